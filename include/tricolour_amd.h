@@ -1,0 +1,204 @@
+/*
+ * tricolour_amd.h -- C ABI of the MI355X-native SumThreshold flagger.
+ *
+ * This is the drop-in boundary for ONE path of ratt-ru/tricolour: the
+ * per-block callable behind tricolour.dask_wrappers.sum_threshold_flagger
+ * (reference tricolour/dask_wrappers.py:23-46), i.e.
+ * tricolour.flagging.sum_threshold_flagger (reference
+ * tricolour/flagging.py:1076-1196) and the window pack / unpack transposes
+ * either side of it (reference tricolour/packing.py:243-278, 369-415).
+ *
+ * Plain pointers and sizes only; no torch / Python types.  All data pointers
+ * are DEVICE pointers (HBM resident); `stream` is a hipStream_t (NULL = the
+ * null stream).  Functions enqueue work on `stream` and return without
+ * synchronising; inputs are never written; outputs and the workspace are
+ * caller-allocated.  Every function returns 0 on success or a TRI_E* code, in
+ * which case tri_last_error() (thread-local) describes the failure.  The
+ * library is re-entrant: it keeps no mutable global state, so concurrent calls
+ * from several host threads (the reference's dask ThreadPool,
+ * apps/tricolour/app.py:266-271) are safe when each uses its own stream and
+ * workspace.
+ */
+#ifndef TRICOLOUR_AMD_H
+#define TRICOLOUR_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRI_MAX_WINDOWS 16
+
+enum tri_status {
+    TRI_OK = 0,
+    TRI_EINVAL = 1,      /* bad shape / NULL pointer -> Python ValueError       */
+    TRI_EUNSUPPORTED = 2,/* parameter combination the reference itself rejects
+                            or that this build does not implement               */
+    TRI_EWORKSPACE = 3,  /* workspace smaller than tri_workspace_bytes(.., 1)   */
+    TRI_EHIP = 4         /* a HIP runtime call failed                           */
+};
+
+enum tri_vis_dtype {
+    TRI_VIS_C64 = 0,     /* interleaved (re, im) float32 -- MS DATA columns     */
+    TRI_VIS_F32 = 1      /* real float32 amplitudes (flagging.py:830-832)       */
+};
+
+/*
+ * Prepared parameters of one sum_threshold_flagger call: the keyword
+ * arguments of flagging.py:1076-1083 after the plain-Python preparation of
+ * flagging.py:1156-1179 (window de-duplication / clipping, frequency chunk
+ * ends).  Build it with tri_prepare_params().
+ */
+typedef struct tri_params {
+    double  outlier_nsigma;
+    int64_t n_windows_time;
+    int64_t windows_time[TRI_MAX_WINDOWS];
+    int64_t n_windows_freq;
+    int64_t windows_freq[TRI_MAX_WINDOWS];
+    double  background_reject;
+    int64_t background_iterations;
+    double  spike_width_time;
+    double  spike_width_freq;
+    int64_t time_extend;
+    int64_t freq_extend;
+    int64_t n_chunk_ends;          /* freq_chunks + 1                          */
+    const int64_t *chunk_ends;     /* HOST pointer, averaged-channel units     */
+    int64_t average_freq;
+    double  flag_all_time_frac;
+    double  flag_all_freq_frac;
+    double  rho;
+    int64_t num_major_iterations;
+} tri_params;
+
+/*
+ * Restates flagging.py:1156-1179: windows_freq = unique(int(ceil(f32(w)) /
+ * average_freq)); freq_chunk_ends = linspace(0, averaged_channels,
+ * freq_chunks + 1).astype(int); windows clipped to <= ntime / <=
+ * averaged_channels.  `chunk_ends_buf` (HOST, capacity `chunk_cap` >=
+ * freq_chunks + 1) receives the chunk ends and is referenced by `out`.
+ * A zero-sized frequency window (possible with average_freq > 1, where the
+ * reference fails with a broadcasting ValueError at flagging.py:663) returns
+ * TRI_EINVAL.
+ */
+int tri_prepare_params(int64_t ntime, int64_t nchan,
+                       double outlier_nsigma,
+                       const double *windows_time, int64_t n_windows_time,
+                       const double *windows_freq, int64_t n_windows_freq,
+                       double background_reject, int64_t background_iterations,
+                       double spike_width_time, double spike_width_freq,
+                       int64_t time_extend, int64_t freq_extend,
+                       int64_t freq_chunks, int64_t average_freq,
+                       double flag_all_time_frac, double flag_all_freq_frac,
+                       double rho, int64_t num_major_iterations,
+                       int64_t *chunk_ends_buf, int64_t chunk_cap,
+                       tri_params *out);
+
+/*
+ * Device workspace needed to process `batch_windows` correlation products
+ * (bl x corr windows) of shape (ntime, nchan) at a time.  The flagger accepts
+ * any workspace >= tri_workspace_bytes(.., 1) and sizes its internal batch to
+ * what it is given; larger batches fill the GPU better.
+ */
+size_t tri_workspace_bytes(int64_t batch_windows, int64_t ntime, int64_t nchan,
+                           const tri_params *p);
+
+/*
+ * Replaces tricolour.flagging.sum_threshold_flagger (flagging.py:1076-1196)
+ * for one window block.
+ *   vis        (n_cp, ntime, nchan) visibilities, C order, dtype `vis_dtype`
+ *              [n_cp = bl * corr after the reshape of flagging.py:1156-1158]
+ *   flags      (n_cp, ntime, nchan) uint8 / bool, non-zero = flagged
+ *   out_flags  (n_cp, ntime, nchan) uint8, receives 0/1: the LAST major
+ *              iteration's flags (flagging.py:1181-1196), not OR-ed with the
+ *              input flags
+ * Bit-exact with the reference executed under its numba JIT.
+ */
+int tri_sum_threshold_flagger(const void *vis, int vis_dtype,
+                              const uint8_t *flags, uint8_t *out_flags,
+                              int64_t n_cp, int64_t ntime, int64_t nchan,
+                              const tri_params *p,
+                              void *workspace, size_t workspace_bytes,
+                              void *stream);
+
+/*
+ * Replaces packing._numba_pack_data (packing.py:243-278): scatter MS rows
+ * (row, chan, corr) into windows (bl, corr, time, chan).  `row_bl` / `row_time`
+ * (int32, length `rows`) give each row's window baseline index and time index
+ * (row_bl < 0: row belongs to no baseline of this block and is skipped); they
+ * replace the reference's O(nbl * rows) antenna matching with a precomputed
+ * row -> (bl, t) map (see tri_row_map in the Python mirror).  Cells no row
+ * maps to keep their prior contents: initialise the windows with
+ * tri_fill_windows (NaN+NaNj / 1, packing.py:97,117).
+ */
+int tri_pack_data(const void *data_c64, const uint8_t *flag,
+                  const int32_t *row_bl, const int32_t *row_time,
+                  int64_t rows, int64_t nchan, int64_t ncorr,
+                  int64_t nbl, int64_t ntime,
+                  void *vis_windows_c64, uint8_t *flag_windows, void *stream);
+
+int tri_fill_windows(void *vis_windows_c64, uint8_t *flag_windows,
+                     int64_t n_elements, void *stream);
+
+/*
+ * Replaces packing._unpack_data / _numpy_unpack_transpose
+ * (packing.py:369-415): gather flag windows (bl, corr, time, chan) back to MS
+ * row order (row, chan, corr); rows with row_bl < 0 are set to 0.
+ */
+int tri_unpack_data(const uint8_t *flag_windows,
+                    const int32_t *row_bl, const int32_t *row_time,
+                    int64_t rows, int64_t nchan, int64_t ncorr,
+                    int64_t nbl, int64_t ntime,
+                    uint8_t *out_flags, void *stream);
+
+/* Thread-local description of the last failure in the calling thread. */
+const char *tri_last_error(void);
+
+/* Library / ABI version (major * 100 + minor). */
+int tri_version(void);
+
+/*
+ * Measurement hooks (used by bench.py and tests only; not part of the
+ * reference's interface).
+ *
+ * tri_bench_sumthreshold runs ONLY the fused SumThreshold column kernel
+ * (clamp + float64 prefix + multi-scale thresholds + flag dilation, all
+ * windows in one pass; flagging.py:582-681) `repeats` times on `stream`,
+ * bracketed by HIP events recorded on that stream, and returns the mean kernel
+ * time in milliseconds through `ms_per_launch`.
+ *   data (n_win, n_line, n_col) float32 residuals; the sequential axis is
+ *        n_line, columns are coalesced
+ *   mad  (n_win, n_col) float64 medians of |data| (NaN = nothing unflagged)
+ *   out  (n_win, n_line, n_col) uint8
+ * `variant`: 0 = best available for these windows, 1 = generic (dynamic
+ * windows, global rings), 2 = register cascade (windows 1,2,4,8 only).
+ */
+int tri_bench_sumthreshold(const float *data, const double *mad, uint8_t *out,
+                           int64_t n_win, int64_t n_line, int64_t n_col,
+                           const int64_t *windows, int64_t n_windows,
+                           double outlier_nsigma, double rho, int variant,
+                           int repeats, float *ms_per_launch, void *stream);
+
+/*
+ * Test hook: tri_sum_threshold_flagger that additionally taps the LAST major
+ * iteration's intermediates of window 0 into caller-provided device buffers
+ * (Fa = averaged channels, N = ntime * Fa):
+ *   dbg_f32: [spec_resid (Fa)][background, FT layout (Fa x ntime)][residual, TF layout (ntime x Fa)]
+ *   dbg_u8 : [spec_flags (Fa)][time_flags TF (N)][freq_flags TF (N)]
+ */
+int tri_sum_threshold_flagger_debug(const void *vis, int vis_dtype,
+                                    const uint8_t *flags, uint8_t *out_flags,
+                                    int64_t n_cp, int64_t ntime, int64_t nchan,
+                                    const tri_params *p,
+                                    void *workspace, size_t workspace_bytes,
+                                    void *stream, float *dbg_f32, uint8_t *dbg_u8);
+
+/* Device amplitude of complex64 samples, the |z| used at flagging.py:856
+ * (libm hypotf semantics); exposed so the tests can pin it (golden G0). */
+int tri_abs_c64(const void *z_c64, float *out, int64_t n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRICOLOUR_AMD_H */

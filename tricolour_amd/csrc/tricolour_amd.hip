@@ -1,0 +1,1515 @@
+// tricolour_amd.hip -- MI355X (gfx950 / CDNA4) SumThreshold RFI flagger.
+//
+// Hand-written HIP implementation of the hot path of ratt-ru/tricolour
+// (reference tricolour/flagging.py:175-976, 1076-1196; packing.py:243-278,
+// 369-415) behind the C ABI of include/tricolour_amd.h.  Not a translation:
+// the reference is a serial per-baseline numba loop nest; here every step is a
+// batched kernel over (window, line) with the window held in HBM in BOTH
+// orientations -- "TF" (time rows, channel columns) and "FT" (channel rows,
+// time columns) -- so that
+//   * every sequential float64 recurrence of the reference (box-filter running
+//     sums, SumThreshold prefix sums, NaN interpolation) runs one thread per
+//     line with the line index on the coalesced axis ("column kernels"), in
+//     exactly the reference's order of operations => bit-exact by
+//     construction, and
+//   * every exact median runs over lines that are contiguous in memory
+//     ("row select": multi-pass radix select on the |x| bit patterns).
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no fast-math: the
+// results must follow IEEE evaluation order).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/tricolour_amd.h"
+
+#define TRI_MAD_NORMAL 1.4826  // flagging.py:22
+
+// ---------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+
+static int set_err(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(expr)                                                          \
+    do {                                                                      \
+        hipError_t e__ = (expr);                                              \
+        if (e__ != hipSuccess)                                                \
+            return set_err(TRI_EHIP, "%s failed: %s (%s:%d)", #expr,          \
+                           hipGetErrorString(e__), __FILE__, __LINE__);       \
+    } while (0)
+
+#define LAUNCHCHK()                                                           \
+    do {                                                                      \
+        hipError_t e__ = hipGetLastError();                                   \
+        if (e__ != hipSuccess)                                                \
+            return set_err(TRI_EHIP, "kernel launch failed: %s (%s:%d)",      \
+                           hipGetErrorString(e__), __FILE__, __LINE__);       \
+    } while (0)
+
+extern "C" const char* tri_last_error(void) { return g_err; }
+extern "C" int tri_version(void) { return 100; }
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------
+// |complex64| with libm hypotf semantics (numba lowers abs(complex64) to
+// hypotf, flagging.py:856): glibc evaluates (float)sqrt((double)x*x +
+// (double)y*y) with the C99 infinity rule.  Products are exact in float64, one
+// rounding in the sum, IEEE sqrt, one narrowing cast.
+__device__ __forceinline__ float tri_hypotf(float re, float im) {
+    if (isinf(re) || isinf(im)) return INFINITY;
+    double s = (double)re * (double)re + (double)im * (double)im;
+    return (float)sqrt(s);
+}
+
+template <int VD>
+__device__ __forceinline__ float load_amp(const void* vis, size_t i) {
+    if (VD == TRI_VIS_C64) {
+        float2 z = reinterpret_cast<const float2*>(vis)[i];
+        return tri_hypotf(z.x, z.y);
+    } else {
+        return fabsf(reinterpret_cast<const float*>(vis)[i]);
+    }
+}
+
+template <int VD>
+__device__ __forceinline__ bool load_isnan(const void* vis, size_t i) {
+    if (VD == TRI_VIS_C64) {
+        float2 z = reinterpret_cast<const float2*>(vis)[i];
+        return isnan(z.x) || isnan(z.y);
+    } else {
+        return isnan(reinterpret_cast<const float*>(vis)[i]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K1  _average_freq (flagging.py:819-875): |vis| -> f32, NaN -> flagged,
+// flagged -> 0, channel averaging by `factor` (f32 accumulation in ascending
+// channel order, f32 / count).  One thread per averaged sample.
+// grid (ceil(T*Fa/256), W)
+// ---------------------------------------------------------------------------
+template <int VD>
+__global__ void k_prepare(const void* __restrict__ vis, const uint8_t* __restrict__ iflags,
+                          float* __restrict__ data, uint8_t* __restrict__ flags,
+                          int T, int F, int Fa, int factor) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t NA = (size_t)T * Fa;
+    if (idx >= NA) return;
+    int t = (int)(idx / Fa), fo = (int)(idx % Fa);
+    size_t w = blockIdx.y;
+    size_t base = w * (size_t)T * F + (size_t)t * F;
+    int f0 = fo * factor;
+    int f1 = min(F, f0 + factor);
+    float sum = 0.0f;
+    int cnt = 0;
+    for (int f = f0; f < f1; f++) {
+        float a = load_amp<VD>(vis, base + f);
+        if (!iflags[base + f] && !isnan(a)) { sum += a; cnt++; }
+    }
+    size_t o = w * NA + idx;
+    if (cnt == 0) { data[o] = 0.0f; flags[o] = 1; }
+    else { data[o] = sum / (float)cnt; flags[o] = 0; }
+}
+
+__global__ void k_abs_c64(const float2* __restrict__ z, float* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = tri_hypotf(z[i].x, z[i].y);
+}
+
+// ---------------------------------------------------------------------------
+// K2  batched tiled transpose  src[W][R][C] -> dst[W][C][R]  (64x64 LDS tile)
+// grid (ceil(C/64), ceil(R/64), W), block (64,4)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void k_transpose(const T* __restrict__ src, T* __restrict__ dst, int R, int C,
+                            size_t src_ws, size_t dst_ws) {
+    __shared__ T tile[64][65];
+    const T* s = src + (size_t)blockIdx.z * src_ws;
+    T* d = dst + (size_t)blockIdx.z * dst_ws;
+    int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    int tx = threadIdx.x, ty = threadIdx.y;
+    for (int j = ty; j < 64; j += 4) {
+        int r = r0 + j, c = c0 + tx;
+        if (r < R && c < C) tile[j][tx] = s[(size_t)r * C + c];
+    }
+    __syncthreads();
+    for (int j = ty; j < 64; j += 4) {
+        int c = c0 + j, r = r0 + tx;
+        if (r < R && c < C) d[(size_t)c * R + r] = tile[tx][j];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K3  segmented exact median of |x| over unflagged samples ("row select").
+// np.median under numba (np/arraymath.py:1365-1399): odd n -> middle element,
+// even n -> f32(a + b) / 2 in float64.  NaN when nothing is unflagged
+// (flagging.py:276-277, 300-301).  |x| of a float32 is a sign-bit clear, so
+// ordering |x| = ordering the low 31 bits as unsigned integers: a 4-digit
+// (7+8+8+8 bit) radix select is exact.
+// One workgroup per segment.  Segment (win, row, g) covers elements
+//   data[win*WSd + row*RS + (seg_start[g] + i)*ES],  i < seg_len[g]
+// (flags likewise with window stride WSf).
+// Output med[(win*R + row)*G + g] (float64).
+// grid (R*G, W), block 256
+// ---------------------------------------------------------------------------
+#define SEL_CACHE 8
+__global__ void __launch_bounds__(256)
+k_median(const float* __restrict__ data, const uint8_t* __restrict__ flags,
+         double* __restrict__ med, size_t WSd, size_t WSf, size_t RS, size_t ES,
+         const int64_t* __restrict__ seg_start, const int64_t* __restrict__ seg_len,
+         int R, int G) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sh_prefix, sh_k, sh_n, sh_cnt, sh_max;
+    const unsigned SENT = 0xFFFFFFFFu;
+    int seg = blockIdx.x;
+    int row = seg / G, g = seg % G;
+    size_t win = blockIdx.y;
+    int64_t len = seg_len[g];
+    size_t rel = (size_t)row * RS + (size_t)seg_start[g] * ES;
+    data += win * WSd + rel;
+    flags += win * WSf + rel;
+    const size_t base = 0;
+    int tid = threadIdx.x;
+    bool cached = len <= (int64_t)SEL_CACHE * 256;
+    unsigned keys[SEL_CACHE];
+    if (cached) {
+#pragma unroll
+        for (int u = 0; u < SEL_CACHE; u++) {
+            int64_t i = (int64_t)u * 256 + tid;
+            unsigned k = SENT;
+            if (i < len) {
+                size_t a = base + (size_t)i * ES;
+                if (!flags[a]) k = __float_as_uint(data[a]) & 0x7FFFFFFFu;
+            }
+            keys[u] = k;
+        }
+    }
+    unsigned prefix = 0, pmask = 0, kk = 0, n = 0;
+    for (int p = 0; p < 4; p++) {
+        int shift = 24 - 8 * p;
+        hist[tid] = 0;
+        __syncthreads();
+        if (cached) {
+#pragma unroll
+            for (int u = 0; u < SEL_CACHE; u++) {
+                unsigned k = keys[u];
+                if (k != SENT && (k & pmask) == prefix) atomicAdd(&hist[(k >> shift) & 0xFFu], 1u);
+            }
+        } else {
+            for (int64_t i = tid; i < len; i += 256) {
+                size_t a = base + (size_t)i * ES;
+                if (!flags[a]) {
+                    unsigned k = __float_as_uint(data[a]) & 0x7FFFFFFFu;
+                    if ((k & pmask) == prefix) atomicAdd(&hist[(k >> shift) & 0xFFu], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            // lane l owns bins 4l..4l+3; wave-wide inclusive scan of lane sums
+            unsigned h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2],
+                     h3 = hist[4 * tid + 3];
+            unsigned s = h0 + h1 + h2 + h3;
+            unsigned inc = s;
+            for (int o = 1; o < 64; o <<= 1) {
+                unsigned v = __shfl_up(inc, o, 64);
+                if (tid >= o) inc += v;
+            }
+            unsigned total = __shfl(inc, 63, 64);
+            unsigned nn = (p == 0) ? total : 0;
+            unsigned ktarget = (p == 0) ? (total >> 1) : sh_k;
+            if (p == 0 && tid == 0) sh_n = total;
+            unsigned exc = inc - s;
+            if (total > 0 && ktarget >= exc && ktarget < inc) {
+                unsigned c = exc;
+                unsigned d;
+                if (ktarget < c + h0) d = 0;
+                else if (ktarget < c + h0 + h1) { d = 1; c += h0; }
+                else if (ktarget < c + h0 + h1 + h2) { d = 2; c += h0 + h1; }
+                else { d = 3; c += h0 + h1 + h2; }
+                sh_prefix = prefix | ((4u * tid + d) << shift);
+                sh_k = ktarget - c;
+            }
+            (void)nn;
+        }
+        __syncthreads();
+        if (p == 0) n = sh_n;
+        if (n == 0) break;
+        prefix = sh_prefix;
+        kk = sh_k;
+        pmask |= 0xFFu << shift;
+        __syncthreads();
+    }
+    (void)kk;
+    size_t oidx = (win * (size_t)R + row) * G + g;
+    if (n == 0) {
+        if (tid == 0) med[oidx] = __longlong_as_double(0x7FF8000000000000LL);
+        return;
+    }
+    unsigned hi = prefix;
+    if (n & 1u) {
+        if (tid == 0) med[oidx] = (double)__uint_as_float(hi);
+        return;
+    }
+    // even count: lo = element of rank n/2 - 1 = max{x < hi} if exactly n/2
+    // elements are below hi, else hi itself (duplicates).
+    if (tid == 0) { sh_cnt = 0; sh_max = 0; }
+    __syncthreads();
+    unsigned cnt = 0, mx = 0;
+    if (cached) {
+#pragma unroll
+        for (int u = 0; u < SEL_CACHE; u++) {
+            unsigned k = keys[u];
+            if (k != SENT && k < hi) { cnt++; mx = max(mx, k); }
+        }
+    } else {
+        for (int64_t i = tid; i < len; i += 256) {
+            size_t a = base + (size_t)i * ES;
+            if (!flags[a]) {
+                unsigned k = __float_as_uint(data[a]) & 0x7FFFFFFFu;
+                if (k < hi) { cnt++; mx = max(mx, k); }
+            }
+        }
+    }
+    if (cnt) { atomicAdd(&sh_cnt, cnt); atomicMax(&sh_max, mx); }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned lo = (sh_cnt == (n >> 1)) ? sh_max : hi;
+        float s = __uint_as_float(lo) + __uint_as_float(hi);  // f32 + f32 -> f32
+        med[oidx] = (double)s / 2.0;                          // f32 / int64 -> f64
+    }
+}
+
+// spec_data[f][w] / spec_flags from the per-channel time medians
+// (flagging.py:258-263): none unflagged -> 0 and flagged.
+// med layout [w][f]; outputs in spectrum layout [Fa][Wn].
+__global__ void k_spec_from_med(const double* __restrict__ med, float* __restrict__ sdata,
+                                uint8_t* __restrict__ sflags, int Fa, int Wn) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)Fa * Wn) return;
+    int f = (int)(idx / Wn), w = (int)(idx % Wn);
+    double m = med[(size_t)w * Fa + f];
+    bool none = isnan(m);
+    sdata[idx] = none ? 0.0f : (float)m;
+    sflags[idx] = none ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------
+// K4  _box_gaussian_filter1d (flagging.py:362-419) along the line axis of a
+// [n][C] array, one thread per (column, image): four running box sums of
+// width 2r+1 over a left-zero-padded line, float64 accumulator, every pass
+// stored as float32 -- in exactly the reference's order (add the leading
+// sample, store, subtract the trailing sample).  The padded line lives in a
+// global scratch buffer buf[P = n + 4r][C] and the passes run in place, as in
+// the reference; the never-written zero padding is synthesised instead of
+// stored (rows below lo_p read as 0).
+//   SRCMODE 0: pass 1 builds weight = !flag / data = flag ? 0 : x on the fly
+//              from (srcData, srcFlags) (masked_gaussian_filter,
+//              flagging.py:500-503).
+//   SRCMODE 1: the unfiltered images were already written into rows
+//              [4r, 4r+n) of bufW / bufO (by the transposing copy).
+// Pass 4 divides by float32(d)**4 (host-computed, square-and-multiply as
+// numba does) and writes rows [0,n) of dstW / dstO.
+// grid (ceil(C/BLK), W, 2 images), block BLK
+// ---------------------------------------------------------------------------
+#define CF_U 8
+template <int SRCMODE>
+__global__ void __launch_bounds__(256)
+k_colfilter(float* __restrict__ bufW, float* __restrict__ bufO,
+            const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags,
+            float* __restrict__ dstW, float* __restrict__ dstO,
+            int n, int C, int r, float denom, size_t bws, size_t sws, size_t dws) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    size_t win = blockIdx.y;
+    const int img = blockIdx.z;  // 0 = weight image, 1 = data image
+    float* buf = (img == 0 ? bufW : bufO) + win * bws + c;
+    float* dst = (img == 0 ? dstW : dstO) + win * dws + c;
+    const float* sd = SRCMODE == 0 ? srcData + win * sws + c : nullptr;
+    const uint8_t* sf = SRCMODE == 0 ? srcFlags + win * sws + c : nullptr;
+    const int R2 = 2 * r, R4 = 4 * r;
+    const int P = n + R4;
+    const size_t Cs = (size_t)C;
+
+    auto rd = [&](int j, int p) -> float {
+        // value of padded[j] as seen by pass p (j in [0, P))
+        if (p == 1) {
+            int jj = j - R4;
+            if (jj < 0) return 0.0f;
+            if (SRCMODE == 0) {
+                bool fl = sf[(size_t)jj * Cs] != 0;
+                if (img == 0) return fl ? 0.0f : 1.0f;
+                return fl ? 0.0f : sd[(size_t)jj * Cs];
+            }
+            return buf[(size_t)j * Cs];
+        }
+        if (p == 2 && j < R2) return 0.0f;
+        return buf[(size_t)j * Cs];
+    };
+
+    for (int p = 1; p <= 4; p++) {
+        double s = 0.0;
+        if (p >= 3) {
+            // flagging.py:404-405: pre-add padded[prev_start .. start + 2r)
+            int i = 0;
+            for (; i + CF_U <= R2; i += CF_U) {
+                float v[CF_U];
+#pragma unroll
+                for (int u = 0; u < CF_U; u++) v[u] = rd(i + u, p);
+#pragma unroll
+                for (int u = 0; u < CF_U; u++) s += (double)v[u];
+            }
+            for (; i < R2; i++) s += (double)rd(i, p);
+        }
+        const int start = (p == 1) ? R2 : 0;
+        const int stop = (p == 4) ? n : (p == 3 ? n + R2 : P);
+        const int tail = n + R2;
+        const int mainEnd = min(tail, stop);
+        int i = start;
+        for (; i + CF_U <= mainEnd; i += CF_U) {
+            float lead[CF_U], prev[CF_U], o[CF_U];
+#pragma unroll
+            for (int u = 0; u < CF_U; u++) lead[u] = rd(i + u + R2, p);
+#pragma unroll
+            for (int u = 0; u < CF_U; u++) prev[u] = rd(i + u, p);
+#pragma unroll
+            for (int u = 0; u < CF_U; u++) {
+                s += (double)lead[u];
+                o[u] = (float)s;
+                s -= (double)prev[u];
+            }
+            if (p < 4) {
+#pragma unroll
+                for (int u = 0; u < CF_U; u++) buf[(size_t)(i + u) * Cs] = o[u];
+            } else {
+#pragma unroll
+                for (int u = 0; u < CF_U; u++) dst[(size_t)(i + u) * Cs] = o[u] / denom;
+            }
+        }
+        for (; i < mainEnd; i++) {
+            float lead = rd(i + R2, p);
+            float prev = rd(i, p);
+            s += (double)lead;
+            float o = (float)s;
+            s -= (double)prev;
+            if (p < 4) buf[(size_t)i * Cs] = o;
+            else dst[(size_t)i * Cs] = o / denom;
+        }
+        // flagging.py:412-416 (no leading sample left)
+        for (i = mainEnd; i < stop; i++) {
+            float prev = rd(i, p);
+            float o = (float)s;
+            s -= (double)prev;
+            if (p < 4) buf[(size_t)i * Cs] = o;
+            else dst[(size_t)i * Cs] = o / denom;
+        }
+    }
+}
+
+// r == 0 on both axes: weight = !flag, data = flag ? 0 : x (flagging.py:500-503
+// followed by the plain copy of flagging.py:465-466).
+__global__ void k_build_wo(const float* __restrict__ data, const uint8_t* __restrict__ flags,
+                           float* __restrict__ w, float* __restrict__ o, size_t nper,
+                           size_t sws, size_t dws) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nper) return;
+    size_t win = blockIdx.y;
+    bool fl = flags[win * sws + i] != 0;
+    w[win * dws + i] = fl ? 0.0f : 1.0f;
+    o[win * dws + i] = fl ? 0.0f : data[win * sws + i];
+}
+
+// ---------------------------------------------------------------------------
+// K5  masked_gaussian_filter tail (flagging.py:506-513) and the background
+// residual (flagging.py:563-566):  bg = w == 0 ? NaN : o / w;
+//   MODE 0: o <- bg          MODE 1: o <- |data - bg|
+// ---------------------------------------------------------------------------
+template <int MODE>
+__global__ void k_masked_div(const float* __restrict__ w, float* __restrict__ o,
+                             const float* __restrict__ data, size_t nper, size_t ws_wo,
+                             size_t ws_data) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nper) return;
+    size_t win = blockIdx.y;
+    float wv = w[win * ws_wo + i];
+    float ov = o[win * ws_wo + i];
+    float bg = (wv == 0.0f) ? NAN : ov / wv;
+    if (MODE == 1) bg = fabsf(data[win * ws_data + i] - bg);
+    o[win * ws_wo + i] = bg;
+}
+
+// flags |= resid > median * (MAD_NORMAL * reject)   (flagging.py:567-574);
+// float32 residual compared in float64; NaN compares false.
+// Array layout [L][C] per window; chunk_of[l] gives the chunk of line index l.
+// thr index: TWOD ? (win*G + g) : (c*G + g)   [spectrum layout: column = window]
+template <bool TWOD>
+__global__ void k_reject(const float* __restrict__ resid, uint8_t* __restrict__ flags,
+                         const double* __restrict__ med, const int* __restrict__ chunk_of,
+                         double scale, int L, int C, int G, size_t ws_resid, size_t ws_flags) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)L * C) return;
+    size_t win = blockIdx.y;
+    int l = (int)(i / C), c = (int)(i % C);
+    int g = chunk_of[l];
+    double m = TWOD ? med[win * G + g] : med[(size_t)c * G + g];
+    double thr = m * scale;
+    if ((double)resid[win * ws_resid + i] > thr) flags[win * ws_flags + i] = 1;
+}
+
+// ---------------------------------------------------------------------------
+// K6  _linearly_interpolate_nans1d (flagging.py:307-344) along the line axis
+// of [L][C], one thread per column.  numba typing: grad = (f32 - f32) / int64
+// -> float64; value = f32(f32 + int64 * f64) evaluated in float64.
+// grid (ceil(C/256), W)
+// ---------------------------------------------------------------------------
+__global__ void k_colinterp(float* __restrict__ a, int L, int C, size_t ws) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float* x = a + (size_t)blockIdx.y * ws + c;
+    const size_t Cs = (size_t)C;
+    int last = -1;       // index of the last valid sample
+    float lastv = 0.0f;
+    int run = 0;         // start of the current NaN run
+    for (int i = 0; i < L; i++) {
+        float v = x[(size_t)i * Cs];
+        if (isnan(v)) continue;
+        if (run < i) {
+            if (last < 0) {
+                for (int j = run; j < i; j++) x[(size_t)j * Cs] = v;  // extrapolate backwards
+            } else {
+                float diff = v - lastv;
+                double grad = (double)diff / (double)(i - last);
+                for (int j = run; j < i; j++)
+                    x[(size_t)j * Cs] = (float)((double)lastv + (double)(j - last) * grad);
+            }
+        }
+        last = i;
+        lastv = v;
+        run = i + 1;
+    }
+    if (run < L) {
+        float fill = last < 0 ? 0.0f : lastv;  // all NaN -> zeros; else extrapolate forwards
+        for (int j = run; j < L; j++) x[(size_t)j * Cs] = fill;
+    }
+}
+
+// out = a - b  (flagging.py:950, 962)
+__global__ void k_sub(const float* __restrict__ a, const float* __restrict__ b,
+                      float* __restrict__ out, size_t nper, size_t ws_a, size_t ws_b,
+                      size_t ws_o) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nper) return;
+    size_t win = blockIdx.y;
+    out[win * ws_o + i] = a[win * ws_a + i] - b[win * ws_b + i];
+}
+
+__global__ void k_or(uint8_t* __restrict__ a, const uint8_t* __restrict__ b, size_t nper,
+                     size_t ws_a, size_t ws_b) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nper) return;
+    size_t win = blockIdx.y;
+    if (b[win * ws_b + i]) a[win * ws_a + i] = 1;
+}
+
+__global__ void k_copy_u8(const uint8_t* __restrict__ a, uint8_t* __restrict__ b, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) b[i] = a[i];
+}
+
+// flags[w][t][f] |= spec[f][w]   (flagging.py:954); spec in spectrum layout
+__global__ void k_or_spec(uint8_t* __restrict__ flags, const uint8_t* __restrict__ spec, int T,
+                          int Fa, int Wn) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)T * Fa) return;
+    size_t win = blockIdx.y;
+    int f = (int)(i % Fa);
+    if (spec[(size_t)f * Wn + win]) flags[win * (size_t)T * Fa + i] = 1;
+}
+
+// ---------------------------------------------------------------------------
+// K7  _sum_threshold1d + _convolve_flags (flagging.py:582-681) along the line
+// axis of [L][C]: one thread per (column, chunk) streams down its padded line
+// ONCE, running all windows as a cascade: stage j ingests position i (clamp
+// with the flags of stages < j, float64 sequential prefix sum), forms the
+// rolling sum S_k = cum[k+w] - cum[k] for k = i + 1 - w from a ring of the
+// last w prefix values, thresholds +S and -S against thr0 / rho^log2(w), and
+// dilates hits over w samples; stage j+1 runs w_j - 1 positions behind so
+// that its clamp sees exactly the flags the reference's window loop would
+// (flagging.py:638-674, window order as given).  Every float64 value is
+// produced by the same operations in the same order as the reference.
+// Input flags are used only in the MAD (flagging.py:622), never OR-ed in.
+//
+// Dynamic variant: arbitrary windows; prefix rings and the position ring of
+// accumulated (pos,neg) bits live in a global scratch laid out
+// [slot][thread] (coalesced).
+// grid (ceil(C/BLK), G, W), block BLK
+// ---------------------------------------------------------------------------
+struct StWin {
+    int nw;
+    int w[TRI_MAX_WINDOWS];
+    double tf[TRI_MAX_WINDOWS];     // rho ** log2(w)           (host libm, flagging.py:641)
+    double scale[TRI_MAX_WINDOWS];  // (double)(float)(1.0 / w) (flagging.py:664)
+    int ringoff[TRI_MAX_WINDOWS];   // slot offset of stage j's prefix ring
+    int ringtot;                    // sum of w
+    int delay[TRI_MAX_WINDOWS + 1]; // D_j = sum_{j'<j} (w_j' - 1)
+    int acccap;                     // >= D_nw + 1
+    int maxw;
+};
+
+__global__ void __launch_bounds__(256)
+k_colst_dyn(const float* __restrict__ data, const double* __restrict__ med,
+            uint8_t* __restrict__ out, double* __restrict__ ringbuf,
+            uint8_t* __restrict__ accbuf, const int64_t* __restrict__ chunk_ends, StWin sw,
+            double thr_scale, int L, int C, int G, size_t ws_data, size_t ws_out) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    int g = blockIdx.y;
+    size_t win = blockIdx.z;
+    int c0 = (int)chunk_ends[g], c1 = (int)chunk_ends[g + 1];
+    if (c1 <= c0) return;
+    // thread-private scratch, [slot][thread]
+    size_t nthreads = (size_t)gridDim.z * G * C;
+    size_t tidg = (win * G + g) * (size_t)C + c;
+    double* ring = ringbuf + tidg;
+    uint8_t* acc = accbuf + tidg;
+    const float* x = data + win * ws_data + c;
+    uint8_t* o = out + win * ws_out + c;
+    const size_t Cs = (size_t)C;
+
+    // flagging.py:622-628
+    float mad = (float)med[(win * (size_t)C + c) * G + g];
+    float thr0 = isnan(mad) ? INFINITY : (float)((double)mad * thr_scale);
+    // flagging.py:630-633 (slicing clamps to the axis length)
+    int p0 = max(c0 - sw.maxw + 1, 0);
+    int p1 = min(c1 + sw.maxw - 1, L);
+    int Lp = p1 - p0;
+
+    const int nw = sw.nw;
+    double thr[TRI_MAX_WINDOWS], cumlast[TRI_MAX_WINDOWS];
+    int sincep[TRI_MAX_WINDOWS], sincen[TRI_MAX_WINDOWS];
+    for (int j = 0; j < nw; j++) {
+        thr[j] = (double)thr0 / sw.tf[j];
+        cumlast[j] = 0.0;
+        sincep[j] = sincen[j] = 1 << 30;
+        ring[(size_t)sw.ringoff[j] * nthreads] = 0.0;  // cum[0] = 0 in slot 0
+    }
+    for (int s = 0; s < sw.acccap; s++) acc[(size_t)s * nthreads] = 0;
+
+    const int total = Lp + sw.delay[nw];
+    for (int n = 0; n < total; n++) {
+        for (int j = 0; j < nw; j++) {
+            const int w = sw.w[j];
+            int i = n - sw.delay[j];      // ingest position
+            if (i < 0) continue;
+            int e = i + 1 - w;            // emit position
+            if (e >= Lp) continue;
+            bool hp = false, hn = false;
+            if (i < Lp) {
+                uint8_t a = acc[(size_t)(i % sw.acccap) * nthreads];
+                float xf = x[(size_t)(p0 + i) * Cs];
+                double clamped = (double)xf;
+                double limit = thr[j];
+                if ((a & 1) && clamped > limit) clamped = limit;
+                else if ((a & 2) && clamped < -limit) clamped = -limit;
+                double cumnew = cumlast[j] + clamped;
+                cumlast[j] = cumnew;
+                size_t slot = (size_t)(sw.ringoff[j] + ((i + 1) % w)) * nthreads;
+                if (e >= 0) {
+                    double S = cumnew - ring[slot];
+                    hp = S * sw.scale[j] > limit;
+                    hn = S * (-sw.scale[j]) > limit;
+                }
+                ring[slot] = cumnew;
+            }
+            if (e >= 0) {
+                sincep[j] = hp ? 0 : min(sincep[j] + 1, 1 << 30);
+                sincen[j] = hn ? 0 : min(sincen[j] + 1, 1 << 30);
+                uint8_t add = (sincep[j] < w ? 1 : 0) | (sincen[j] < w ? 2 : 0);
+                if (add) acc[(size_t)(e % sw.acccap) * nthreads] |= add;
+            }
+        }
+        int ef = n - sw.delay[nw];        // position final after the last stage
+        if (ef >= 0 && ef < Lp) {
+            size_t aslot = (size_t)(ef % sw.acccap) * nthreads;
+            uint8_t a = acc[aslot];
+            acc[aslot] = 0;               // recycle the slot
+            int pos = p0 + ef;
+            if (pos >= c0 && pos < c1) o[(size_t)pos * Cs] = a ? 1 : 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K8  _combine_flags + _unaverage_freq (flagging.py:784-918), TF layout.
+// comb[t][fa] = any over t' in [t - e/2, t - e/2 + e) of (spec|time|freq).
+// ---------------------------------------------------------------------------
+__global__ void k_combine(const uint8_t* __restrict__ spec, const uint8_t* __restrict__ tflags,
+                          const uint8_t* __restrict__ fflags, uint8_t* __restrict__ comb, int T,
+                          int Fa, int Wn, int lo, int hi) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)T * Fa) return;
+    size_t win = blockIdx.y;
+    int t = (int)(i / Fa), f = (int)(i % Fa);
+    size_t base = win * (size_t)T * Fa;
+    int t0 = max(t + lo, 0), t1 = min(t + hi, T);
+    uint8_t v = 0;
+    if (t1 > t0) {
+        if (spec[(size_t)f * Wn + win]) v = 1;
+        for (int tt = t0; tt < t1 && !v; tt++) {
+            size_t a = base + (size_t)tt * Fa + f;
+            v = (tflags[a] | fflags[a]) ? 1 : 0;
+        }
+    }
+    comb[base + i] = v;
+}
+
+// dil[t][f] = any comb[t][f'/avg] for f' in [f - e/2, f - e/2 + e) clamped;
+// per-row and per-column counts of dil (flagging.py:896-908).
+// grid (ceil(F/256), T, W), block 256
+__global__ void k_unaverage(const uint8_t* __restrict__ comb, uint8_t* __restrict__ dil,
+                            int* __restrict__ rowcnt, int* __restrict__ colcnt, int T, int Fa,
+                            int F, int avg, int lo, int hi) {
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    int t = blockIdx.y;
+    size_t win = blockIdx.z;
+    int v = 0;
+    if (f < F) {
+        int f0 = max(f + lo, 0), f1 = min(f + hi, F);
+        const uint8_t* row = comb + win * (size_t)T * Fa + (size_t)t * Fa;
+        for (int ff = f0; ff < f1 && !v; ff++) v = row[ff / avg] ? 1 : 0;
+        dil[win * (size_t)T * F + (size_t)t * F + f] = (uint8_t)v;
+        if (v) atomicAdd(&colcnt[win * (size_t)F + f], 1);
+    }
+    // row count: wave ballot + one atomic per wave
+    unsigned long long b = __ballot(v);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&rowcnt[win * (size_t)T + t], __popcll(b));
+}
+
+// out = dil | row rule | column rule | isnan(vis); iter |= out
+// (flagging.py:910-918, 777-781, 1193)
+template <int VD>
+__global__ void k_final(const uint8_t* __restrict__ dil, const int* __restrict__ rowcnt,
+                        const int* __restrict__ colcnt, const void* __restrict__ vis,
+                        uint8_t* __restrict__ out, uint8_t* __restrict__ iter, int T, int F,
+                        double row_limit, double col_limit, int update_iter) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)T * F) return;
+    size_t win = blockIdx.y;
+    int t = (int)(i / F), f = (int)(i % F);
+    size_t a = win * (size_t)T * F + i;
+    bool v = dil[a] != 0;
+    v = v || ((double)rowcnt[win * (size_t)T + t] > row_limit);
+    v = v || ((double)colcnt[win * (size_t)F + f] > col_limit);
+    v = v || load_isnan<VD>(vis, a);
+    out[a] = v ? 1 : 0;
+    if (update_iter && v) iter[a] = 1;
+}
+
+// ---------------------------------------------------------------------------
+// pack / unpack (packing.py:243-278, 369-415) with a precomputed row map
+// ---------------------------------------------------------------------------
+__global__ void k_fill_windows(float2* __restrict__ vis, uint8_t* __restrict__ flags, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    vis[i] = make_float2(NAN, NAN);
+    flags[i] = 1;
+}
+
+// one thread per (row, chan); loops over corr. grid (ceil(nchan/256), rows)
+__global__ void k_pack(const float2* __restrict__ data, const uint8_t* __restrict__ flag,
+                       const int32_t* __restrict__ row_bl, const int32_t* __restrict__ row_time,
+                       int nchan, int ncorr, int nbl, int ntime, float2* __restrict__ vw,
+                       uint8_t* __restrict__ fw) {
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    size_t r = blockIdx.y;
+    if (f >= nchan) return;
+    int bl = row_bl[r], t = row_time[r];
+    if (bl < 0 || bl >= nbl || t < 0 || t >= ntime) return;
+    for (int c = 0; c < ncorr; c++) {
+        size_t i = (r * nchan + f) * (size_t)ncorr + c;
+        size_t o = (((size_t)bl * ncorr + c) * ntime + t) * (size_t)nchan + f;
+        vw[o] = data[i];
+        fw[o] = flag[i];
+    }
+}
+
+__global__ void k_unpack(const uint8_t* __restrict__ fw, const int32_t* __restrict__ row_bl,
+                         const int32_t* __restrict__ row_time, int nchan, int ncorr, int nbl,
+                         int ntime, uint8_t* __restrict__ out) {
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    size_t r = blockIdx.y;
+    if (f >= nchan) return;
+    int bl = row_bl[r], t = row_time[r];
+    bool ok = !(bl < 0 || bl >= nbl || t < 0 || t >= ntime);
+    for (int c = 0; c < ncorr; c++) {
+        size_t i = (r * nchan + f) * (size_t)ncorr + c;
+        out[i] = ok ? fw[(((size_t)bl * ncorr + c) * ntime + t) * (size_t)nchan + f] : 0;
+    }
+}
+
+// ===========================================================================
+// host side
+// ===========================================================================
+namespace {
+
+struct Bump {
+    char* base;
+    size_t cap, off;
+    bool dry;
+    Bump(void* b, size_t c, bool d) : base((char*)b), cap(c), off(0), dry(d) {}
+    template <typename T>
+    T* get(size_t count) {
+        size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+        size_t o = off;
+        off += bytes;
+        if (dry) return nullptr;
+        return reinterpret_cast<T*>(base + o);
+    }
+};
+
+// int(0.5 * sqrt(12 sigma^2 / passes + 1)), flagging.py:451
+int64_t box_radius(double sigma) {
+    return (int64_t)(0.5 * std::sqrt(12.0 * (sigma * sigma) / 4.0 + 1.0));
+}
+
+// float32(d) ** 4 as numba evaluates it: square-and-multiply in float32
+// (numba cpython/numbers.py:207-245)
+float box_denominator(int64_t r) {
+    volatile float a = (float)(2 * r + 1);
+    volatile float a2 = a * a;
+    volatile float a4 = a2 * a2;
+    volatile float res = 1.0f * a4;
+    return res;
+}
+
+struct Plan {
+    int64_t T, F, Fa, avg, G;
+    int64_t r0max, r1max;   // largest box radii along time / frequency
+    int64_t PT, PF;         // padded line lengths
+    int nit;                // background_iterations
+    StWin swT, swF;
+};
+
+int make_stwin(const int64_t* w, int64_t nw, double rho, StWin* s) {
+    memset(s, 0, sizeof(*s));
+    if (nw <= 0) return set_err(TRI_EINVAL, "no SumThreshold window fits the data (np.max of an empty window list)");
+    if (nw > TRI_MAX_WINDOWS) return set_err(TRI_EINVAL, "too many windows");
+    s->nw = (int)nw;
+    int off = 0, d = 0, maxw = 0;
+    for (int j = 0; j < nw; j++) {
+        if (w[j] <= 0) return set_err(TRI_EINVAL, "SumThreshold window of size %lld (the reference fails here with a broadcasting ValueError)", (long long)w[j]);
+        s->w[j] = (int)w[j];
+        s->tf[j] = std::pow(rho, std::log2((double)w[j]));
+        s->scale[j] = (double)(float)(1.0 / (double)w[j]);
+        s->ringoff[j] = off;
+        off += (int)w[j];
+        s->delay[j] = d;
+        d += (int)w[j] - 1;
+        maxw = std::max(maxw, (int)w[j]);
+    }
+    s->delay[nw] = d;
+    s->ringtot = off;
+    s->acccap = d + 1;
+    s->maxw = maxw;
+    return TRI_OK;
+}
+
+int make_plan(int64_t T, int64_t F, const tri_params* p, Plan* pl) {
+    if (T <= 0 || F <= 0) return set_err(TRI_EINVAL, "empty window (ntime=%lld, nchan=%lld)", (long long)T, (long long)F);
+    if (p->average_freq < 1 || p->average_freq > 255) return set_err(TRI_EUNSUPPORTED, "average_freq must be in [1, 255]");
+    if (p->n_chunk_ends < 2 || !p->chunk_ends) return set_err(TRI_EINVAL, "freq_chunks must be >= 1");
+    if (p->background_iterations < 0 || p->num_major_iterations < 0) return set_err(TRI_EINVAL, "negative iteration count");
+    pl->T = T; pl->F = F; pl->avg = p->average_freq;
+    pl->Fa = (F + pl->avg - 1) / pl->avg;
+    pl->G = p->n_chunk_ends - 1;
+    for (int64_t g = 0; g < p->n_chunk_ends; g++) {
+        if (p->chunk_ends[g] < 0 || p->chunk_ends[g] > pl->Fa || (g > 0 && p->chunk_ends[g] < p->chunk_ends[g - 1]))
+            return set_err(TRI_EINVAL, "freq chunk ends must be non-decreasing within [0, averaged channels]");
+    }
+    if (p->chunk_ends[0] != 0 || p->chunk_ends[pl->G] != pl->Fa) return set_err(TRI_EINVAL, "freq chunk ends must start at 0 and end at the averaged channel count");
+    pl->nit = (int)p->background_iterations;
+    int64_t emax = std::max<int64_t>(pl->nit, 1);
+    pl->r0max = box_radius((double)emax * p->spike_width_time);
+    pl->r1max = box_radius((double)emax * p->spike_width_freq);
+    if (pl->r0max > (1 << 20) || pl->r1max > (1 << 20)) return set_err(TRI_EUNSUPPORTED, "spike width too large");
+    pl->PT = T + 4 * pl->r0max;
+    pl->PF = pl->Fa + 4 * pl->r1max;
+    int rc = make_stwin(p->windows_time, p->n_windows_time, p->rho, &pl->swT);
+    if (rc) return rc;
+    rc = make_stwin(p->windows_freq, p->n_windows_freq, p->rho, &pl->swF);
+    if (rc) return rc;
+    if (T * pl->Fa >= ((int64_t)1 << 31) || T * F >= ((int64_t)1 << 31))
+        return set_err(TRI_EUNSUPPORTED, "a single window must hold fewer than 2^31 samples");
+    return TRI_OK;
+}
+
+// Workspace carve-up for a batch of Wb windows.  `dry` only measures.
+#define TRI_MAX_CHUNKS 255
+struct ChunkTab {
+    int n;                       // number of chunk ends
+    int64_t ends[TRI_MAX_CHUNKS + 1];
+};
+
+struct Ws {
+    // per-window images
+    float *dataTF, *dataFT, *Aw, *Ao, *Bw, *Bo;
+    uint8_t *iter, *flagsTF, *flagsFT, *bgfTF, *bgfFT, *tflTF, *fflFT, *fflTF, *comb, *dil;
+    int *rowcnt, *colcnt;
+    double* med;      // medians: max(Fa, T*G) per window
+    // spectrum layout [Fa][Wb]
+    float *sdata, *sw, *so, *sres;
+    uint8_t *sflags, *sbgf, *sout;
+    double* smed;     // [Wb][G]
+    // SumThreshold scratch
+    double* ring;
+    uint8_t* acc;
+    // small tables (device)
+    int64_t* d_chunk_ends;   // G+1, averaged-channel units
+    int64_t* d_tends;        // {0, T}
+    int64_t *segC_start, *segC_len;   // chunk segments in line units
+    int64_t *segB_start, *segB_len;   // chunk blocks of the FT layout (x T)
+    int64_t *segT_start, *segT_len;   // the single segment [0, T)
+    int* d_chunk_of;         // Fa
+    size_t total;
+};
+
+static void carve(const Plan& pl, int64_t Wb, void* base, size_t cap, bool dry, Ws* ws) {
+    Bump b(base, cap, dry);
+    size_t W = (size_t)Wb, T = (size_t)pl.T, F = (size_t)pl.F, Fa = (size_t)pl.Fa, G = (size_t)pl.G;
+    size_t N = T * Fa;
+    // small tables first so that their addresses do not depend on the batch
+    ws->d_chunk_ends = b.get<int64_t>(G + 1);
+    ws->d_tends = b.get<int64_t>(2);
+    ws->segC_start = b.get<int64_t>(G);
+    ws->segC_len = b.get<int64_t>(G);
+    ws->segB_start = b.get<int64_t>(G);
+    ws->segB_len = b.get<int64_t>(G);
+    ws->segT_start = b.get<int64_t>(1);
+    ws->segT_len = b.get<int64_t>(1);
+    ws->d_chunk_of = b.get<int>(Fa);
+    ws->iter = b.get<uint8_t>(W * T * F);
+    ws->dataTF = b.get<float>(W * N);
+    ws->dataFT = b.get<float>(W * N);
+    ws->Aw = b.get<float>(W * (size_t)pl.PT * Fa);
+    ws->Ao = b.get<float>(W * (size_t)pl.PT * Fa);
+    ws->Bw = b.get<float>(W * (size_t)pl.PF * T);
+    ws->Bo = b.get<float>(W * (size_t)pl.PF * T);
+    ws->flagsTF = b.get<uint8_t>(W * N);
+    ws->flagsFT = b.get<uint8_t>(W * N);
+    ws->bgfTF = b.get<uint8_t>(W * N);
+    ws->bgfFT = b.get<uint8_t>(W * N);
+    ws->tflTF = b.get<uint8_t>(W * N);
+    ws->fflFT = b.get<uint8_t>(W * N);
+    ws->fflTF = b.get<uint8_t>(W * N);
+    ws->comb = b.get<uint8_t>(W * N);
+    ws->dil = b.get<uint8_t>(W * T * F);
+    ws->rowcnt = b.get<int>(W * T);
+    ws->colcnt = b.get<int>(W * F);
+    ws->med = b.get<double>(W * std::max(Fa, T * G));
+    size_t PS = (size_t)pl.PF;  // spectrum padded length
+    ws->sdata = b.get<float>(Fa * W);
+    ws->sw = b.get<float>(PS * W);
+    ws->so = b.get<float>(PS * W);
+    ws->sres = b.get<float>(Fa * W);
+    ws->sflags = b.get<uint8_t>(Fa * W);
+    ws->sbgf = b.get<uint8_t>(Fa * W);
+    ws->sout = b.get<uint8_t>(Fa * W);
+    ws->smed = b.get<double>(W * G);
+    // SumThreshold scratch: one slot set per (window, chunk, column) thread
+    size_t thrT = W * Fa, thrF = W * T * G;
+    size_t ringn = std::max(thrT * (size_t)pl.swT.ringtot, thrF * (size_t)pl.swF.ringtot);
+    size_t accn = std::max(thrT * (size_t)pl.swT.acccap, thrF * (size_t)pl.swF.acccap);
+    ws->ring = b.get<double>(ringn);
+    ws->acc = b.get<uint8_t>(accn);
+    ws->total = b.off;
+}
+
+static inline dim3 grid1(size_t n, size_t W) { return dim3((unsigned)cdiv((int64_t)n, 256), (unsigned)W, 1); }
+
+}  // namespace
+
+__global__ void k_tables(ChunkTab ct, int T, int Fa, int64_t* chunk_ends, int64_t* tends,
+                         int64_t* segC_start, int64_t* segC_len, int64_t* segB_start,
+                         int64_t* segB_len, int64_t* segT_start, int64_t* segT_len,
+                         int* chunk_of) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int G = ct.n - 1;
+    if (i <= G) chunk_ends[i] = ct.ends[i];
+    if (i < G) {
+        segC_start[i] = ct.ends[i];
+        segC_len[i] = ct.ends[i + 1] - ct.ends[i];
+        segB_start[i] = ct.ends[i] * T;
+        segB_len[i] = (ct.ends[i + 1] - ct.ends[i]) * T;
+    }
+    if (i == 0) { tends[0] = 0; tends[1] = T; segT_start[0] = 0; segT_len[0] = T; }
+    if (i < Fa) {
+        int g = 0;
+        // chunk containing channel i: ends[g] <= i < ends[g+1] (skips empty chunks)
+        while (g < G - 1 && !(i >= ct.ends[g] && i < ct.ends[g + 1])) g++;
+        chunk_of[i] = g;
+    }
+}
+
+// copies column `col` of a [L][C] array into a contiguous vector (debug taps)
+__global__ void k_gather_col_f32(const float* __restrict__ a, float* __restrict__ out, int L, int C, int col) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < L) out[i] = a[(size_t)i * C + col];
+}
+__global__ void k_gather_col_u8(const uint8_t* __restrict__ a, uint8_t* __restrict__ out, int L, int C, int col) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < L) out[i] = a[(size_t)i * C + col];
+}
+__global__ void k_normalise_flags(const uint8_t* __restrict__ a, uint8_t* __restrict__ b, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) b[i] = a[i] ? 1 : 0;
+}
+
+extern "C" size_t tri_workspace_bytes(int64_t batch_windows, int64_t ntime, int64_t nchan,
+                                      const tri_params* p) {
+    Plan pl;
+    if (!p || batch_windows <= 0 || make_plan(ntime, nchan, p, &pl) != TRI_OK) return 0;
+    Ws ws;
+    carve(pl, batch_windows, nullptr, 0, true, &ws);
+    return ws.total;
+}
+
+extern "C" int tri_prepare_params(int64_t ntime, int64_t nchan, double outlier_nsigma,
+                                  const double* windows_time, int64_t n_windows_time,
+                                  const double* windows_freq, int64_t n_windows_freq,
+                                  double background_reject, int64_t background_iterations,
+                                  double spike_width_time, double spike_width_freq,
+                                  int64_t time_extend, int64_t freq_extend, int64_t freq_chunks,
+                                  int64_t average_freq, double flag_all_time_frac,
+                                  double flag_all_freq_frac, double rho,
+                                  int64_t num_major_iterations, int64_t* chunk_ends_buf,
+                                  int64_t chunk_cap, tri_params* out) {
+    if (!out || !chunk_ends_buf) return set_err(TRI_EINVAL, "NULL output");
+    if (ntime <= 0 || nchan <= 0) return set_err(TRI_EINVAL, "empty window");
+    if (average_freq < 1) return set_err(TRI_EINVAL, "average_freq must be >= 1");
+    if (freq_chunks < 1) return set_err(TRI_EINVAL, "freq_chunks must be >= 1");
+    if (chunk_cap < freq_chunks + 1) return set_err(TRI_EINVAL, "chunk_ends_buf too small");
+    if (n_windows_time > TRI_MAX_WINDOWS || n_windows_freq > TRI_MAX_WINDOWS || n_windows_time < 0 || n_windows_freq < 0)
+        return set_err(TRI_EINVAL, "at most %d windows per axis", TRI_MAX_WINDOWS);
+    memset(out, 0, sizeof(*out));
+    int64_t fa = (nchan + average_freq - 1) / average_freq;
+    // flagging.py:1160-1162: float32 ceil, float32 division, truncation, unique
+    std::vector<int64_t> wf;
+    for (int64_t i = 0; i < n_windows_freq; i++) {
+        float v = std::ceil((float)windows_freq[i]) / (float)average_freq;
+        wf.push_back((int64_t)v);
+    }
+    std::sort(wf.begin(), wf.end());
+    wf.erase(std::unique(wf.begin(), wf.end()), wf.end());
+    // flagging.py:1172-1173: linspace(0, fa, freq_chunks + 1).astype(int)
+    double step = (double)fa / (double)freq_chunks;
+    for (int64_t i = 0; i <= freq_chunks; i++) chunk_ends_buf[i] = (int64_t)((double)i * step);
+    chunk_ends_buf[freq_chunks] = fa;
+    // flagging.py:1176-1179
+    out->n_windows_time = 0;
+    for (int64_t i = 0; i < n_windows_time; i++)
+        if (windows_time[i] <= (double)ntime) out->windows_time[out->n_windows_time++] = (int64_t)windows_time[i];
+    out->n_windows_freq = 0;
+    for (size_t i = 0; i < wf.size(); i++)
+        if (wf[i] <= fa) out->windows_freq[out->n_windows_freq++] = wf[i];
+    for (int64_t i = 0; i < out->n_windows_freq; i++)
+        if (out->windows_freq[i] <= 0)
+            return set_err(TRI_EINVAL, "windows_freq / average_freq produced a window of size %lld; the reference fails here (operands could not be broadcast together, flagging.py:663)", (long long)out->windows_freq[i]);
+    for (int64_t i = 0; i < out->n_windows_time; i++)
+        if (out->windows_time[i] <= 0) return set_err(TRI_EINVAL, "windows_time must be positive");
+    out->outlier_nsigma = outlier_nsigma;
+    out->background_reject = background_reject;
+    out->background_iterations = background_iterations;
+    out->spike_width_time = spike_width_time;
+    out->spike_width_freq = spike_width_freq;
+    out->time_extend = time_extend;
+    out->freq_extend = freq_extend;
+    out->n_chunk_ends = freq_chunks + 1;
+    out->chunk_ends = chunk_ends_buf;
+    out->average_freq = average_freq;
+    out->flag_all_time_frac = flag_all_time_frac;
+    out->flag_all_freq_frac = flag_all_freq_frac;
+    out->rho = rho;
+    out->num_major_iterations = num_major_iterations;
+    return TRI_OK;
+}
+
+namespace {
+
+struct Debug {
+    float* f32;     // [spec_resid Fa][background FT Fa*T][residual TF T*Fa]
+    uint8_t* u8;    // [spec_flags Fa][time_flags TF][freq_flags TF]
+};
+
+struct Run {
+    hipStream_t st;
+    Plan pl;
+    Ws ws;
+    const tri_params* p;
+    int64_t Wb;      // windows in this batch
+    Debug* dbg;      // taps of window 0 (tests only), or NULL
+};
+
+int launch_median(const Run& r, const float* data, const uint8_t* flags, double* med, size_t WSd,
+                  size_t WSf, size_t RS, size_t ES, const int64_t* seg_start,
+                  const int64_t* seg_len, int R, int G, int64_t W) {
+    if ((int64_t)R * G <= 0 || W <= 0) return TRI_OK;
+    if ((int64_t)R * G > 0x7FFFFFFF || W > 65535) return set_err(TRI_EUNSUPPORTED, "median grid too large");
+    hipLaunchKernelGGL(k_median, dim3((unsigned)(R * G), (unsigned)W), dim3(256), 0, r.st, data,
+                       flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
+    LAUNCHCHK();
+    return TRI_OK;
+}
+
+int launch_colfilter(const Run& r, int srcmode, float* bufW, float* bufO, const float* srcData,
+                     const uint8_t* srcFlags, float* dstW, float* dstO, int n, int C, int rad,
+                     size_t bws, size_t sws, size_t dws, int64_t W) {
+    float denom = box_denominator(rad);
+    int blk = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
+    dim3 grid((unsigned)cdiv(C, blk), (unsigned)W, 2);
+    if (srcmode == 0)
+        hipLaunchKernelGGL(k_colfilter<0>, grid, dim3(blk), 0, r.st, bufW, bufO, srcData, srcFlags,
+                           dstW, dstO, n, C, rad, denom, bws, sws, dws);
+    else
+        hipLaunchKernelGGL(k_colfilter<1>, grid, dim3(blk), 0, r.st, bufW, bufO, srcData, srcFlags,
+                           dstW, dstO, n, C, rad, denom, bws, sws, dws);
+    LAUNCHCHK();
+    return TRI_OK;
+}
+
+int launch_colst(const Run& r, const StWin& sw, const float* data, const double* med,
+                 uint8_t* out, const int64_t* d_chunk_ends, int L, int C, int G, size_t ws_data,
+                 size_t ws_out, int64_t W) {
+    double thr_scale = r.p->outlier_nsigma * TRI_MAD_NORMAL;  // flagging.py:623
+    int blk = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
+    dim3 grid((unsigned)cdiv(C, blk), (unsigned)G, (unsigned)W);
+    hipLaunchKernelGGL(k_colst_dyn, grid, dim3(blk), 0, r.st, data, med, out, r.ws.ring, r.ws.acc,
+                       d_chunk_ends, sw, thr_scale, L, C, G, ws_data, ws_out);
+    LAUNCHCHK();
+    return TRI_OK;
+}
+
+template <typename T>
+int launch_transpose(const Run& r, const T* src, T* dst, int R, int C, size_t sws, size_t dws,
+                     int64_t W) {
+    dim3 grid((unsigned)cdiv(C, 64), (unsigned)cdiv(R, 64), (unsigned)W);
+    hipLaunchKernelGGL(k_transpose<T>, grid, dim3(64, 4), 0, r.st, src, dst, R, C, sws, dws);
+    LAUNCHCHK();
+    return TRI_OK;
+}
+
+// _get_background2d (flagging.py:516-579) for the median spectra of the batch,
+// held in spectrum layout [Fa][Wb] (line axis = channel, column = window).
+// Result: rows [0,Fa) of ws.so hold the background.
+int spectrum_background(const Run& r) {
+    const Plan& pl = r.pl;
+    const Ws& ws = r.ws;
+    int Fa = (int)pl.Fa, Wn = (int)r.Wb, G = (int)pl.G;
+    size_t nS = (size_t)Fa * Wn;
+    hipLaunchKernelGGL(k_copy_u8, dim3((unsigned)cdiv(nS, 256)), dim3(256), 0, r.st, ws.sflags, ws.sbgf, nS);
+    LAUNCHCHK();
+    double rej = TRI_MAD_NORMAL * r.p->background_reject;  // flagging.py:568
+    for (int ext = pl.nit; ext >= 0; ext--) {
+        bool final_pass = ext == 0;
+        double sigma = (double)(final_pass ? 1 : ext) * r.p->spike_width_freq;  // flagging.py:554, 576
+        int rad = (int)box_radius(sigma);
+        if (rad > 0) {
+            int rc = launch_colfilter(r, 0, ws.sw, ws.so, ws.sdata, ws.sbgf, ws.sw, ws.so, Fa, Wn, rad, 0, 0, 0, 1);
+            if (rc) return rc;
+        } else {
+            hipLaunchKernelGGL(k_build_wo, grid1(nS, 1), dim3(256), 0, r.st, ws.sdata, ws.sbgf, ws.sw, ws.so, nS, (size_t)0, (size_t)0);
+            LAUNCHCHK();
+        }
+        if (final_pass) {
+            hipLaunchKernelGGL(k_masked_div<0>, grid1(nS, 1), dim3(256), 0, r.st, ws.sw, ws.so, ws.sdata, nS, (size_t)0, (size_t)0);
+            LAUNCHCHK();
+        } else {
+            hipLaunchKernelGGL(k_masked_div<1>, grid1(nS, 1), dim3(256), 0, r.st, ws.sw, ws.so, ws.sdata, nS, (size_t)0, (size_t)0);
+            LAUNCHCHK();
+            // per (window, chunk) median of the residual: element (f, w) at f*Wn + w
+            // -> row = w (RS 1), element stride Wn
+            int rc = launch_median(r, ws.so, ws.sbgf, ws.smed, 0, 0, 1, (size_t)Wn, ws.segC_start, ws.segC_len, Wn, G, 1);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_reject<false>, grid1(nS, 1), dim3(256), 0, r.st, ws.so, ws.sbgf, ws.smed, ws.d_chunk_of, rej, Fa, Wn, G, (size_t)0, (size_t)0);
+            LAUNCHCHK();
+        }
+    }
+    hipLaunchKernelGGL(k_colinterp, dim3((unsigned)cdiv(Wn, 256), 1), dim3(256), 0, r.st, ws.so, Fa, Wn, (size_t)0);
+    LAUNCHCHK();
+    return TRI_OK;
+}
+
+// _get_background2d (flagging.py:516-579) for every window of the batch.
+// In: dataTF / dataFT, flagsTF (spectral flags already OR-ed in).  Out: the
+// background in FT layout in rows [0,Fa) of ws.Bo (window stride PF*T).
+int background2d(const Run& r) {
+    const Plan& pl = r.pl;
+    const Ws& ws = r.ws;
+    int T = (int)pl.T, Fa = (int)pl.Fa, G = (int)pl.G;
+    int64_t W = r.Wb;
+    size_t N = (size_t)T * Fa;
+    size_t wsA = (size_t)pl.PT * Fa, wsB = (size_t)pl.PF * T;
+    hipLaunchKernelGGL(k_copy_u8, dim3((unsigned)cdiv(N * W, 256)), dim3(256), 0, r.st, ws.flagsTF, ws.bgfTF, N * (size_t)W);
+    LAUNCHCHK();
+    int rc = launch_transpose<uint8_t>(r, ws.bgfTF, ws.bgfFT, T, Fa, N, N, W);
+    if (rc) return rc;
+    double rej = TRI_MAD_NORMAL * r.p->background_reject;
+    for (int ext = pl.nit; ext >= 0; ext--) {
+        bool final_pass = ext == 0;
+        double e = (double)(final_pass ? 1 : ext);
+        int r0 = (int)box_radius(e * r.p->spike_width_time);
+        int r1 = (int)box_radius(e * r.p->spike_width_freq);
+        // --- time axis (TF layout: line = time, column = channel) ---
+        if (r0 > 0) {
+            rc = launch_colfilter(r, 0, ws.Aw, ws.Ao, ws.dataTF, ws.bgfTF, ws.Aw, ws.Ao, T, Fa, r0, wsA, N, wsA, W);
+            if (rc) return rc;
+        } else {
+            hipLaunchKernelGGL(k_build_wo, grid1(N, W), dim3(256), 0, r.st, ws.dataTF, ws.bgfTF, ws.Aw, ws.Ao, N, N, wsA);
+            LAUNCHCHK();
+        }
+        // --- to FT layout, into rows [4 r1, 4 r1 + Fa) of the padded buffers ---
+        size_t off = (size_t)4 * r1 * T;
+        rc = launch_transpose<float>(r, ws.Aw, ws.Bw + off, T, Fa, wsA, wsB, W);
+        if (rc) return rc;
+        rc = launch_transpose<float>(r, ws.Ao, ws.Bo + off, T, Fa, wsA, wsB, W);
+        if (rc) return rc;
+        // --- frequency axis (FT layout: line = channel, column = time) ---
+        if (r1 > 0) {
+            rc = launch_colfilter(r, 1, ws.Bw, ws.Bo, nullptr, nullptr, ws.Bw, ws.Bo, Fa, T, r1, wsB, 0, wsB, W);
+            if (rc) return rc;
+        }
+        if (final_pass) {
+            hipLaunchKernelGGL(k_masked_div<0>, grid1(N, W), dim3(256), 0, r.st, ws.Bw, ws.Bo, ws.dataFT, N, wsB, N);
+            LAUNCHCHK();
+        } else {
+            hipLaunchKernelGGL(k_masked_div<1>, grid1(N, W), dim3(256), 0, r.st, ws.Bw, ws.Bo, ws.dataFT, N, wsB, N);
+            LAUNCHCHK();
+            // block medians over (all times) x (chunk channels): contiguous in FT
+            rc = launch_median(r, ws.Bo, ws.bgfFT, ws.med, wsB, N, 0, 1, ws.segB_start, ws.segB_len, 1, G, W);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_reject<true>, grid1(N, W), dim3(256), 0, r.st, ws.Bo, ws.bgfFT, ws.med, ws.d_chunk_of, rej, Fa, T, G, wsB, N);
+            LAUNCHCHK();
+            rc = launch_transpose<uint8_t>(r, ws.bgfFT, ws.bgfTF, Fa, T, N, N, W);
+            if (rc) return rc;
+        }
+    }
+    hipLaunchKernelGGL(k_colinterp, dim3((unsigned)cdiv(T, 256), (unsigned)W), dim3(256), 0, r.st, ws.Bo, Fa, T, wsB);
+    LAUNCHCHK();
+    return TRI_OK;
+}
+
+// One major iteration (_get_flags_impl, flagging.py:745-781) for a batch.
+template <int VD>
+int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_flags, bool update_iter, bool tap) {
+    const Plan& pl = r.pl;
+    const Ws& ws = r.ws;
+    const tri_params* p = r.p;
+    int T = (int)pl.T, F = (int)pl.F, Fa = (int)pl.Fa, G = (int)pl.G;
+    int64_t W = r.Wb;
+    int Wn = (int)W;
+    size_t N = (size_t)T * Fa, NF = (size_t)T * F;
+    size_t wsB = (size_t)pl.PF * T;
+    int rc;
+
+    // flagging.py:756  _average_freq
+    hipLaunchKernelGGL(k_prepare<VD>, grid1(N, W), dim3(256), 0, r.st, vis, iter_flags, ws.dataTF, ws.flagsTF, T, F, Fa, (int)pl.avg);
+    LAUNCHCHK();
+    rc = launch_transpose<float>(r, ws.dataTF, ws.dataFT, T, Fa, N, N, W);
+    if (rc) return rc;
+    rc = launch_transpose<uint8_t>(r, ws.flagsTF, ws.flagsFT, T, Fa, N, N, W);
+    if (rc) return rc;
+
+    // flagging.py:944  _time_median: rows of the FT layout are contiguous in time
+    rc = launch_median(r, ws.dataFT, ws.flagsFT, ws.med, N, N, (size_t)T, 1, ws.segT_start, ws.segT_len, Fa, 1, W);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_spec_from_med, dim3((unsigned)cdiv((size_t)Fa * Wn, 256)), dim3(256), 0, r.st, ws.med, ws.sdata, ws.sflags, Fa, Wn);
+    LAUNCHCHK();
+
+    // flagging.py:945-952  spectrum background, subtraction, SumThreshold
+    rc = spectrum_background(r);
+    if (rc) return rc;
+    size_t nS = (size_t)Fa * Wn;
+    hipLaunchKernelGGL(k_sub, grid1(nS, 1), dim3(256), 0, r.st, ws.sdata, ws.so, ws.sres, nS, (size_t)0, (size_t)0, (size_t)0);
+    LAUNCHCHK();
+    rc = launch_median(r, ws.sres, ws.sflags, ws.smed, 0, 0, 1, (size_t)Wn, ws.segC_start, ws.segC_len, Wn, G, 1);
+    if (rc) return rc;
+    rc = launch_colst(r, pl.swF, ws.sres, ws.smed, ws.sout, ws.d_chunk_ends, Fa, Wn, G, 0, 0, 1);
+    if (rc) return rc;
+
+    // flagging.py:954  flags |= spec_flags
+    hipLaunchKernelGGL(k_or_spec, grid1(N, W), dim3(256), 0, r.st, ws.flagsTF, ws.sout, T, Fa, Wn);
+    LAUNCHCHK();
+
+    // flagging.py:957-962  2-D background (FT layout, ws.Bo), then the residual
+    rc = background2d(r);
+    if (rc) return rc;
+    if (tap && r.dbg) {
+        HIPCHK(hipMemcpyAsync(r.dbg->f32 + Fa, ws.Bo, N * sizeof(float), hipMemcpyDeviceToDevice, r.st));
+    }
+    hipLaunchKernelGGL(k_sub, grid1(N, W), dim3(256), 0, r.st, ws.dataFT, ws.Bo, ws.Bo, N, N, wsB, wsB);
+    LAUNCHCHK();
+    float* residFT = ws.Bo;   // window stride wsB
+    float* residTF = ws.Aw;   // window stride N (the time-axis scratch is free again)
+    rc = launch_transpose<float>(r, residFT, residTF, Fa, T, wsB, N, W);
+    if (rc) return rc;
+
+    // flagging.py:964  SumThreshold along time.  MAD per channel over time =
+    // contiguous rows of the FT layout; flags = input | spectral flags.
+    rc = launch_transpose<uint8_t>(r, ws.flagsTF, ws.flagsFT, T, Fa, N, N, W);
+    if (rc) return rc;
+    rc = launch_median(r, residFT, ws.flagsFT, ws.med, wsB, N, (size_t)T, 1, ws.segT_start, ws.segT_len, Fa, 1, W);
+    if (rc) return rc;
+    rc = launch_colst(r, pl.swT, residTF, ws.med, ws.tflTF, ws.d_tends, T, Fa, 1, N, N, W);
+    if (rc) return rc;
+
+    // flagging.py:967-969  flags |= time_flags; SumThreshold along frequency.
+    // MAD per (time, chunk) = contiguous row segments of the TF layout.
+    hipLaunchKernelGGL(k_or, grid1(N, W), dim3(256), 0, r.st, ws.flagsTF, ws.tflTF, N, N, N);
+    LAUNCHCHK();
+    rc = launch_median(r, residTF, ws.flagsTF, ws.med, N, N, (size_t)Fa, 1, ws.segC_start, ws.segC_len, T, G, W);
+    if (rc) return rc;
+    rc = launch_colst(r, pl.swF, residFT, ws.med, ws.fflFT, ws.d_chunk_ends, Fa, T, G, wsB, N, W);
+    if (rc) return rc;
+    rc = launch_transpose<uint8_t>(r, ws.fflFT, ws.fflTF, Fa, T, N, N, W);
+    if (rc) return rc;
+
+    if (tap && r.dbg) {
+        hipLaunchKernelGGL(k_gather_col_f32, dim3((unsigned)cdiv(Fa, 256)), dim3(256), 0, r.st, ws.sres, r.dbg->f32, Fa, Wn, 0);
+        hipLaunchKernelGGL(k_gather_col_u8, dim3((unsigned)cdiv(Fa, 256)), dim3(256), 0, r.st, ws.sout, r.dbg->u8, Fa, Wn, 0);
+        LAUNCHCHK();
+        HIPCHK(hipMemcpyAsync(r.dbg->f32 + Fa + N, residTF, N * sizeof(float), hipMemcpyDeviceToDevice, r.st));
+        HIPCHK(hipMemcpyAsync(r.dbg->u8 + Fa, ws.tflTF, N, hipMemcpyDeviceToDevice, r.st));
+        HIPCHK(hipMemcpyAsync(r.dbg->u8 + Fa + N, ws.fflTF, N, hipMemcpyDeviceToDevice, r.st));
+    }
+
+    // flagging.py:973  _combine_flags (time smearing)
+    {
+        int64_t e = p->time_extend;
+        int64_t half = e >= 0 ? e / 2 : -((-e + 1) / 2);   // Python floor division
+        int lo = (int)-half, hi = (int)(-half + e);
+        hipLaunchKernelGGL(k_combine, grid1(N, W), dim3(256), 0, r.st, ws.sout, ws.tflTF, ws.fflTF, ws.comb, T, Fa, Wn, lo, hi);
+        LAUNCHCHK();
+    }
+    // flagging.py:975  _unaverage_freq (replication, frequency smearing, counts)
+    {
+        int64_t e = p->freq_extend;
+        int64_t half = e >= 0 ? e / 2 : -((-e + 1) / 2);
+        int lo = (int)-half, hi = (int)(-half + e);
+        HIPCHK(hipMemsetAsync(ws.rowcnt, 0, (size_t)W * T * sizeof(int), r.st));
+        HIPCHK(hipMemsetAsync(ws.colcnt, 0, (size_t)W * F * sizeof(int), r.st));
+        dim3 grid((unsigned)cdiv(F, 256), (unsigned)T, (unsigned)W);
+        hipLaunchKernelGGL(k_unaverage, grid, dim3(256), 0, r.st, ws.comb, ws.dil, ws.rowcnt, ws.colcnt, T, Fa, F, (int)pl.avg, lo, hi);
+        LAUNCHCHK();
+    }
+    // flagging.py:910-918 whole-row / whole-column rules; :777-781 NaN OR; :1193
+    double row_limit = p->flag_all_freq_frac * (double)F;
+    double col_limit = (double)T * p->flag_all_time_frac;
+    hipLaunchKernelGGL(k_final<VD>, grid1(NF, W), dim3(256), 0, r.st, ws.dil, ws.rowcnt, ws.colcnt, vis, out_flags, iter_flags, T, F, row_limit, col_limit, update_iter ? 1 : 0);
+    LAUNCHCHK();
+    return TRI_OK;
+}
+
+int flagger_impl(const void* vis, int vis_dtype, const uint8_t* flags, uint8_t* out_flags,
+                 int64_t n_cp, int64_t T, int64_t F, const tri_params* p, void* workspace,
+                 size_t workspace_bytes, void* stream, Debug* dbg) {
+    if (!vis || !flags || !out_flags || !p) return set_err(TRI_EINVAL, "NULL pointer argument");
+    if (n_cp < 0) return set_err(TRI_EINVAL, "negative window count");
+    if (vis_dtype != TRI_VIS_C64 && vis_dtype != TRI_VIS_F32) return set_err(TRI_EUNSUPPORTED, "vis dtype must be complex64 or float32");
+    Run r;
+    r.st = (hipStream_t)stream;
+    r.p = p;
+    r.dbg = dbg;
+    int rc = make_plan(T, F, p, &r.pl);
+    if (rc) return rc;
+    if (r.pl.G > TRI_MAX_CHUNKS) return set_err(TRI_EUNSUPPORTED, "at most %d frequency chunks", TRI_MAX_CHUNKS);
+    if (n_cp == 0) return TRI_OK;
+    if (!workspace) return set_err(TRI_EWORKSPACE, "NULL workspace");
+    if (((uintptr_t)workspace & 255) != 0) return set_err(TRI_EINVAL, "workspace must be 256-byte aligned");
+    // largest batch the workspace admits (the carve-up is monotone in Wb)
+    Ws probe;
+    carve(r.pl, 1, nullptr, 0, true, &probe);
+    if (probe.total > workspace_bytes)
+        return set_err(TRI_EWORKSPACE, "workspace of %zu bytes is smaller than the %zu needed for one window", workspace_bytes, probe.total);
+    int64_t lo = 1, hi = std::min<int64_t>(n_cp, 16384);
+    while (lo < hi) {
+        int64_t mid = (lo + hi + 1) / 2;
+        carve(r.pl, mid, nullptr, 0, true, &probe);
+        if (probe.total <= workspace_bytes) lo = mid; else hi = mid - 1;
+    }
+    int64_t Wb = lo;
+    carve(r.pl, Wb, workspace, workspace_bytes, false, &r.ws);
+
+    // device tables
+    ChunkTab ct;
+    ct.n = (int)p->n_chunk_ends;
+    for (int i = 0; i < ct.n; i++) ct.ends[i] = p->chunk_ends[i];
+    {
+        int nthr = (int)std::max<int64_t>(r.pl.Fa, ct.n);
+        hipLaunchKernelGGL(k_tables, dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, r.st, ct, (int)T, (int)r.pl.Fa,
+                           r.ws.d_chunk_ends, r.ws.d_tends, r.ws.segC_start, r.ws.segC_len, r.ws.segB_start,
+                           r.ws.segB_len, r.ws.segT_start, r.ws.segT_len, r.ws.d_chunk_of);
+        LAUNCHCHK();
+    }
+    size_t NF = (size_t)T * F;
+    size_t esz = vis_dtype == TRI_VIS_C64 ? 8 : 4;
+    if (p->num_major_iterations == 0)
+        HIPCHK(hipMemsetAsync(out_flags, 0, (size_t)n_cp * NF, r.st));
+    for (int64_t w0 = 0; w0 < n_cp; w0 += Wb) {
+        r.Wb = std::min(Wb, n_cp - w0);
+        const char* vis_b = (const char*)vis + (size_t)w0 * NF * esz;
+        uint8_t* out_b = out_flags + (size_t)w0 * NF;
+        size_t nb = (size_t)r.Wb * NF;
+        // flagging.py:1182  iter_flags = flags.copy()  (non-zero = flagged)
+        hipLaunchKernelGGL(k_normalise_flags, dim3((unsigned)cdiv(nb, 256)), dim3(256), 0, r.st, flags + (size_t)w0 * NF, r.ws.iter, nb);
+        LAUNCHCHK();
+        for (int64_t it = 0; it < p->num_major_iterations; it++) {
+            bool last = it == p->num_major_iterations - 1;
+            bool tap = last && w0 == 0;
+            if (vis_dtype == TRI_VIS_C64) rc = run_iteration<TRI_VIS_C64>(r, vis_b, r.ws.iter, out_b, !last, tap);
+            else rc = run_iteration<TRI_VIS_F32>(r, vis_b, r.ws.iter, out_b, !last, tap);
+            if (rc) return rc;
+        }
+    }
+    return TRI_OK;
+}
+
+}  // namespace
+
+extern "C" int tri_sum_threshold_flagger(const void* vis, int vis_dtype, const uint8_t* flags,
+                                         uint8_t* out_flags, int64_t n_cp, int64_t ntime,
+                                         int64_t nchan, const tri_params* p, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+    return flagger_impl(vis, vis_dtype, flags, out_flags, n_cp, ntime, nchan, p, workspace,
+                        workspace_bytes, stream, nullptr);
+}
+
+// Test hook: as above, additionally taps the last major iteration's
+// intermediates of window 0 into caller-provided device buffers:
+//   dbg_f32: [spec_resid (Fa)][background, FT layout (Fa*T)][residual, TF layout (T*Fa)]
+//   dbg_u8 : [spec_flags (Fa)][time_flags TF (T*Fa)][freq_flags TF (T*Fa)]
+extern "C" int tri_sum_threshold_flagger_debug(const void* vis, int vis_dtype, const uint8_t* flags,
+                                               uint8_t* out_flags, int64_t n_cp, int64_t ntime,
+                                               int64_t nchan, const tri_params* p, void* workspace,
+                                               size_t workspace_bytes, void* stream,
+                                               float* dbg_f32, uint8_t* dbg_u8) {
+    Debug d{dbg_f32, dbg_u8};
+    return flagger_impl(vis, vis_dtype, flags, out_flags, n_cp, ntime, nchan, p, workspace,
+                        workspace_bytes, stream, (dbg_f32 && dbg_u8) ? &d : nullptr);
+}
+
+extern "C" int tri_abs_c64(const void* z, float* out, int64_t n, void* stream) {
+    if (!z || !out || n < 0) return set_err(TRI_EINVAL, "bad argument");
+    if (n == 0) return TRI_OK;
+    hipLaunchKernelGGL(k_abs_c64, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (const float2*)z, out, (size_t)n);
+    LAUNCHCHK();
+    return TRI_OK;
+}
+
+extern "C" int tri_fill_windows(void* vis_windows_c64, uint8_t* flag_windows, int64_t n, void* stream) {
+    if (!vis_windows_c64 || !flag_windows || n < 0) return set_err(TRI_EINVAL, "bad argument");
+    if (n == 0) return TRI_OK;
+    hipLaunchKernelGGL(k_fill_windows, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (float2*)vis_windows_c64, flag_windows, (size_t)n);
+    LAUNCHCHK();
+    return TRI_OK;
+}
+
+extern "C" int tri_pack_data(const void* data_c64, const uint8_t* flag, const int32_t* row_bl,
+                             const int32_t* row_time, int64_t rows, int64_t nchan, int64_t ncorr,
+                             int64_t nbl, int64_t ntime, void* vis_windows_c64,
+                             uint8_t* flag_windows, void* stream) {
+    if (!data_c64 || !flag || !row_bl || !row_time || !vis_windows_c64 || !flag_windows)
+        return set_err(TRI_EINVAL, "NULL pointer argument");
+    if (rows < 0 || nchan <= 0 || ncorr <= 0 || nbl < 0 || ntime < 0) return set_err(TRI_EINVAL, "bad shape");
+    if (rows == 0) return TRI_OK;
+    if (rows > 0x7FFFFFFF) return set_err(TRI_EUNSUPPORTED, "too many rows in one call");
+    dim3 grid((unsigned)cdiv(nchan, 256), 1, 1);
+    // gridDim.y is limited to 65535: walk the rows in slabs
+    for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+        int64_t nr = std::min<int64_t>(65535, rows - r0);
+        grid.y = (unsigned)nr;
+        hipLaunchKernelGGL(k_pack, grid, dim3(256), 0, (hipStream_t)stream,
+                           (const float2*)data_c64 + (size_t)r0 * nchan * ncorr, flag + (size_t)r0 * nchan * ncorr,
+                           row_bl + r0, row_time + r0, (int)nchan, (int)ncorr, (int)nbl, (int)ntime,
+                           (float2*)vis_windows_c64, flag_windows);
+        LAUNCHCHK();
+    }
+    return TRI_OK;
+}
+
+extern "C" int tri_unpack_data(const uint8_t* flag_windows, const int32_t* row_bl,
+                               const int32_t* row_time, int64_t rows, int64_t nchan, int64_t ncorr,
+                               int64_t nbl, int64_t ntime, uint8_t* out_flags, void* stream) {
+    if (!flag_windows || !row_bl || !row_time || !out_flags) return set_err(TRI_EINVAL, "NULL pointer argument");
+    if (rows < 0 || nchan <= 0 || ncorr <= 0 || nbl < 0 || ntime < 0) return set_err(TRI_EINVAL, "bad shape");
+    dim3 grid((unsigned)cdiv(nchan, 256), 1, 1);
+    for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+        int64_t nr = std::min<int64_t>(65535, rows - r0);
+        grid.y = (unsigned)nr;
+        hipLaunchKernelGGL(k_unpack, grid, dim3(256), 0, (hipStream_t)stream, flag_windows, row_bl + r0, row_time + r0,
+                           (int)nchan, (int)ncorr, (int)nbl, (int)ntime, out_flags + (size_t)r0 * nchan * ncorr);
+        LAUNCHCHK();
+    }
+    return TRI_OK;
+}
+
+extern "C" int tri_bench_sumthreshold(const float* data, const double* mad, uint8_t* out,
+                                      int64_t n_win, int64_t n_line, int64_t n_col,
+                                      const int64_t* windows, int64_t n_windows,
+                                      double outlier_nsigma, double rho, int variant, int repeats,
+                                      float* ms_per_launch, void* stream) {
+    if (!data || !mad || !out || !windows || !ms_per_launch) return set_err(TRI_EINVAL, "NULL pointer argument");
+    if (n_win <= 0 || n_line <= 0 || n_col <= 0 || repeats <= 0 || n_win > 65535) return set_err(TRI_EINVAL, "bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    StWin sw;
+    int rc = make_stwin(windows, n_windows, rho, &sw);
+    if (rc) return rc;
+    double thr_scale = outlier_nsigma * TRI_MAD_NORMAL;
+    size_t nthreads = (size_t)n_win * n_col;
+    double* ring = nullptr;
+    uint8_t* acc = nullptr;
+    int64_t* d_ends = nullptr;
+    HIPCHK(hipMalloc(&ring, nthreads * sw.ringtot * sizeof(double)));
+    HIPCHK(hipMalloc(&acc, nthreads * sw.acccap));
+    HIPCHK(hipMalloc(&d_ends, 2 * sizeof(int64_t)));
+    int64_t ends[2] = {0, n_line};
+    HIPCHK(hipMemcpyAsync(d_ends, ends, sizeof(ends), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    int C = (int)n_col, L = (int)n_line;
+    int blk = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
+    dim3 grid((unsigned)cdiv(C, blk), 1, (unsigned)n_win);
+    size_t ws = (size_t)n_line * n_col;
+    (void)variant;
+    HIPCHK(hipEventRecord(e0, st));
+    for (int i = 0; i < repeats; i++) {
+        hipLaunchKernelGGL(k_colst_dyn, grid, dim3(blk), 0, st, data, mad, out, ring, acc, d_ends, sw, thr_scale, L, C, 1, ws, ws);
+    }
+    HIPCHK(hipEventRecord(e1, st));
+    HIPCHK(hipEventSynchronize(e1));
+    LAUNCHCHK();
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *ms_per_launch = ms / repeats;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(ring);
+    (void)hipFree(acc);
+    (void)hipFree(d_ends);
+    return TRI_OK;
+}
