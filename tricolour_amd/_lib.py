@@ -1,0 +1,141 @@
+"""ctypes binding of the C ABI in ``include/tricolour_amd.h``.
+
+The shared library is built in-tree (``tricolour_amd/libtricolour_amd.so``)
+by :func:`build` with ``hipcc --offload-arch=gfx950``; it is the ONLY compute
+path of this package -- there is no CPU or PyTorch fallback, and loading
+fails loudly when the library is missing.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtricolour_amd.so")
+SOURCES = [os.path.join(_HERE, "csrc", "tricolour_amd.hip")]
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "tricolour_amd.h")
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17",
+               # IEEE evaluation order: no FMA contraction, no fast-math;
+               # correctly rounded float32 division / sqrt
+               "-ffp-contract=off", "-fno-fast-math",
+               "-fhip-fp32-correctly-rounded-divide-sqrt"]
+
+TRI_OK, TRI_EINVAL, TRI_EUNSUPPORTED, TRI_EWORKSPACE, TRI_EHIP = range(5)
+TRI_VIS_C64, TRI_VIS_F32 = 0, 1
+TRI_MAX_WINDOWS = 16
+
+
+class TriParams(C.Structure):
+    _fields_ = [
+        ("outlier_nsigma", C.c_double),
+        ("n_windows_time", C.c_int64),
+        ("windows_time", C.c_int64 * TRI_MAX_WINDOWS),
+        ("n_windows_freq", C.c_int64),
+        ("windows_freq", C.c_int64 * TRI_MAX_WINDOWS),
+        ("background_reject", C.c_double),
+        ("background_iterations", C.c_int64),
+        ("spike_width_time", C.c_double),
+        ("spike_width_freq", C.c_double),
+        ("time_extend", C.c_int64),
+        ("freq_extend", C.c_int64),
+        ("n_chunk_ends", C.c_int64),
+        ("chunk_ends", C.POINTER(C.c_int64)),
+        ("average_freq", C.c_int64),
+        ("flag_all_time_frac", C.c_double),
+        ("flag_all_freq_frac", C.c_double),
+        ("rho", C.c_double),
+        ("num_major_iterations", C.c_int64),
+    ]
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(s) > t for s in SOURCES + [HEADER])
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP extension for gfx950 (cross-compiles without a GPU)."""
+    if not (force or needs_build()):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+_SIGNATURES = {
+    "tri_prepare_params": (C.c_int, [C.c_int64, C.c_int64, C.c_double,
+                                     C.POINTER(C.c_double), C.c_int64,
+                                     C.POINTER(C.c_double), C.c_int64,
+                                     C.c_double, C.c_int64, C.c_double, C.c_double,
+                                     C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                     C.c_double, C.c_double, C.c_double, C.c_int64,
+                                     C.POINTER(C.c_int64), C.c_int64,
+                                     C.POINTER(TriParams)]),
+    "tri_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64,
+                                         C.POINTER(TriParams)]),
+    "tri_sum_threshold_flagger": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                            C.c_int64, C.c_int64, C.c_int64,
+                                            C.POINTER(TriParams), C.c_void_p,
+                                            C.c_size_t, C.c_void_p]),
+    "tri_sum_threshold_flagger_debug": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p,
+                                                  C.c_void_p, C.c_int64, C.c_int64,
+                                                  C.c_int64, C.POINTER(TriParams),
+                                                  C.c_void_p, C.c_size_t, C.c_void_p,
+                                                  C.c_void_p, C.c_void_p]),
+    "tri_pack_data": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tri_fill_windows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "tri_unpack_data": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                  C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                  C.c_void_p, C.c_void_p]),
+    "tri_last_error": (C.c_char_p, []),
+    "tri_version": (C.c_int, []),
+    "tri_bench_sumthreshold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                         C.c_int64, C.c_int64, C.POINTER(C.c_int64),
+                                         C.c_int64, C.c_double, C.c_double, C.c_int,
+                                         C.c_int, C.POINTER(C.c_float), C.c_void_p]),
+    "tri_abs_c64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+
+
+def lib():
+    """Loads the extension; raises if it is missing (no fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "tricolour_amd: HIP extension %s is missing -- run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)" % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc == TRI_OK:
+        return
+    msg = lib().tri_last_error().decode("utf-8", "replace")
+    if rc == TRI_EINVAL:
+        raise ValueError(msg)
+    if rc == TRI_EUNSUPPORTED:
+        raise NotImplementedError(msg)
+    if rc == TRI_EWORKSPACE:
+        raise MemoryError(msg)
+    raise RuntimeError(msg)

@@ -1,0 +1,239 @@
+"""Host-side mirror of ``tricolour.flagging.sum_threshold_flagger``.
+
+Same name, keyword arguments, defaults, return value and error behaviour as
+the reference (``tricolour/flagging.py:1076-1196``); the numerics run in the
+HIP extension through the C ABI (``include/tricolour_amd.h``).  PyTorch is
+only used to own device memory and the HIP stream.
+
+* ``numpy`` in -> ``numpy`` out (H2D, run, D2H);
+* ``torch`` ROCm tensors in -> ``torch.bool`` tensor out on the same device,
+  zero-copy, enqueued on the current stream.
+
+There is no CPU path: without a GPU (or without the built extension) the
+call raises ``RuntimeError``.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+from tricolour_amd import _lib
+
+_tls = threading.local()
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _require_gpu():
+    torch = _torch()
+    _lib.lib()  # fail loudly if the extension is missing
+    if not torch.cuda.is_available():
+        raise RuntimeError("tricolour_amd needs a ROCm GPU (MI355X / gfx950); "
+                           "no device is visible and there is no CPU fallback")
+    return torch
+
+
+def prepare_params(ntime, nchan, outlier_nsigma=4.5,
+                   windows_time=[1, 2, 4, 8], windows_freq=[1, 2, 4, 8],
+                   background_reject=2.0, background_iterations=1,
+                   spike_width_time=12.5, spike_width_freq=10.0,
+                   time_extend=3, freq_extend=3,
+                   freq_chunks=10, average_freq=1,
+                   flag_all_time_frac=0.6, flag_all_freq_frac=0.8,
+                   rho=1.3, num_major_iterations=5):
+    """The plain-Python preparation of ``flagging.py:1156-1179`` (window
+    de-duplication and clipping, frequency chunk ends), done by the library's
+    ``tri_prepare_params``.  Returns a ``TriParams`` (keeps its chunk buffer
+    alive) -- usable without a GPU."""
+    lib = _lib.lib()
+    wt = (C.c_double * max(len(windows_time), 1))(*[float(w) for w in windows_time])
+    wf = (C.c_double * max(len(windows_freq), 1))(*[float(w) for w in windows_freq])
+    freq_chunks = int(freq_chunks)
+    buf = (C.c_int64 * (max(freq_chunks, 0) + 1))()
+    p = _lib.TriParams()
+    _lib.check(lib.tri_prepare_params(
+        int(ntime), int(nchan), float(outlier_nsigma),
+        wt, len(windows_time), wf, len(windows_freq),
+        float(background_reject), int(background_iterations),
+        float(spike_width_time), float(spike_width_freq),
+        int(time_extend), int(freq_extend), freq_chunks, int(average_freq),
+        float(flag_all_time_frac), float(flag_all_freq_frac), float(rho),
+        int(num_major_iterations), buf, len(buf), C.byref(p)))
+    p._chunk_buf = buf
+    return p
+
+
+def _workspace(torch, device, nbytes):
+    """Per-thread, per-device workspace tensor (grown on demand): calls from
+    the threads of a dask ThreadPool never share scratch memory."""
+    cache = getattr(_tls, "ws", None)
+    if cache is None:
+        cache = _tls.ws = {}
+    key = (device.type, device.index)
+    t = cache.get(key)
+    if t is None or t.numel() < nbytes:
+        cache[key] = None
+        t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        cache[key] = t
+    return t
+
+
+def release_workspace():
+    """Drops this thread's cached device workspace."""
+    _tls.ws = {}
+
+
+def _workspace_budget(torch, device):
+    env = os.environ.get("TRICOLOUR_AMD_WORKSPACE_GB")
+    if env:
+        return int(float(env) * (1 << 30))
+    free, _total = torch.cuda.mem_get_info(device)
+    cached = getattr(_tls, "ws", {}).get((device.type, device.index))
+    have = cached.numel() if cached is not None else 0
+    return max(int(0.6 * free), have)
+
+
+def _pick_batch(lib, p, n_cp, T, F, budget):
+    one = lib.tri_workspace_bytes(1, T, F, C.byref(p))
+    if one == 0:
+        # let the flagger produce the precise error message
+        return 1, 256
+    if one > budget:
+        raise MemoryError("tricolour_amd: one (%d x %d) window needs %.1f MiB of "
+                          "workspace, more than the %.1f MiB budget"
+                          % (T, F, one / 2**20, budget / 2**20))
+    lo, hi = 1, max(1, min(n_cp, 4096))
+    while lo < hi:
+        mid = (lo + hi + 1) // 2
+        if lib.tri_workspace_bytes(mid, T, F, C.byref(p)) <= budget:
+            lo = mid
+        else:
+            hi = mid - 1
+    return lo, lib.tri_workspace_bytes(lo, T, F, C.byref(p))
+
+
+def _as_device_inputs(torch, vis, flags):
+    """Returns (vis_tensor, flags_u8_tensor, vis_dtype_code, from_numpy)."""
+    from_numpy = isinstance(vis, np.ndarray) or isinstance(flags, np.ndarray)
+    device = None
+    if torch.is_tensor(vis) and vis.is_cuda:
+        device = vis.device
+    elif torch.is_tensor(flags) and flags.is_cuda:
+        device = flags.device
+    else:
+        device = torch.device("cuda", torch.cuda.current_device())
+
+    def to_t(a):
+        if isinstance(a, np.ndarray):
+            return torch.from_numpy(np.ascontiguousarray(a)).to(device, non_blocking=False)
+        if torch.is_tensor(a):
+            return a.to(device)
+        return torch.as_tensor(np.asarray(a)).to(device)
+
+    v = to_t(vis)
+    f = to_t(flags)
+    if v.dtype == torch.complex64:
+        code = _lib.TRI_VIS_C64
+    elif v.dtype == torch.float32:
+        code = _lib.TRI_VIS_F32
+    elif v.dtype == torch.float64:
+        # |x| of a float64 enters the reference's float32 accumulator through
+        # one round-to-nearest (flagging.py:856-859), which is what the cast
+        # does when no channel averaging follows
+        code = -64
+    else:
+        raise TypeError("tricolour_amd.sum_threshold_flagger: visibilities must be "
+                        "complex64 or float32 (got %s)" % v.dtype)
+    if f.dtype == torch.bool:
+        f8 = f.contiguous().view(torch.uint8)
+    elif f.dtype in (torch.uint8, torch.int8):
+        f8 = f.contiguous().view(torch.uint8)
+    else:
+        f8 = (f != 0).view(torch.uint8)   # flagging.py:833-835: non-zero = flagged
+    return v.contiguous(), f8, code, from_numpy, device
+
+
+def sum_threshold_flagger(vis, flags, outlier_nsigma=4.5,
+                          windows_time=[1, 2, 4, 8], windows_freq=[1, 2, 4, 8],
+                          background_reject=2.0, background_iterations=1,
+                          spike_width_time=12.5, spike_width_freq=10.0,
+                          time_extend=3, freq_extend=3,
+                          freq_chunks=10, average_freq=1,
+                          flag_all_time_frac=0.6, flag_all_freq_frac=0.8,
+                          rho=1.3, num_major_iterations=5, _debug=None):
+    """
+    Flagger that uses the SumThreshold method (Offringa, A., MNRAS, 405,
+    155-167, 2010) to detect spikes in both frequency and time axes --
+    MI355X implementation of ``tricolour.flagging.sum_threshold_flagger``
+    (reference ``tricolour/flagging.py:1076-1196``), same arguments:
+
+    vis : (bl, corr, time, chan) complex64 (or float32 amplitudes)
+    flags : same shape, bool (any integer type: non-zero = flagged)
+
+    Returns the flags found by the LAST major iteration (not OR-ed with the
+    input flags), bool, same 4-D shape; inputs are never modified.
+    """
+    torch = _require_gpu()
+    lib = _lib.lib()
+    if tuple(vis.shape) != tuple(flags.shape):
+        raise ValueError("shape mismatch")           # flagging.py:840-841
+    if len(vis.shape) != 4:
+        raise ValueError("not enough values to unpack (expected 4, got %d)"
+                         % len(vis.shape))            # flagging.py:1156
+    nbl, ncorr, ntime, nchan = (int(s) for s in vis.shape)
+    p = prepare_params(ntime, nchan, outlier_nsigma, windows_time, windows_freq,
+                       background_reject, background_iterations, spike_width_time,
+                       spike_width_freq, time_extend, freq_extend, freq_chunks,
+                       average_freq, flag_all_time_frac, flag_all_freq_frac, rho,
+                       num_major_iterations)
+    v, f8, code, from_numpy, device = _as_device_inputs(torch, vis, flags)
+    if code == -64:
+        if int(average_freq) != 1:
+            raise NotImplementedError("float64 visibilities with average_freq > 1")
+        v = v.abs().to(torch.float32)
+        code = _lib.TRI_VIS_F32
+    n_cp = nbl * ncorr
+    with torch.cuda.device(device):
+        out = torch.empty((nbl, ncorr, ntime, nchan), dtype=torch.uint8, device=device)
+        if n_cp > 0 and ntime > 0 and nchan > 0:
+            budget = _workspace_budget(torch, device)
+            _batch, nbytes = _pick_batch(lib, p, n_cp, ntime, nchan, budget)
+            ws = _workspace(torch, device, nbytes)
+            stream = torch.cuda.current_stream(device).cuda_stream
+            if _debug is None:
+                rc = lib.tri_sum_threshold_flagger(v.data_ptr(), code, f8.data_ptr(),
+                                                   out.data_ptr(), n_cp, ntime, nchan,
+                                                   C.byref(p), ws.data_ptr(), ws.numel(),
+                                                   stream)
+            else:
+                fa = (nchan + int(average_freq) - 1) // int(average_freq)
+                n = ntime * fa
+                dbg_f = torch.zeros(fa + 2 * n, dtype=torch.float32, device=device)
+                dbg_u = torch.zeros(fa + 2 * n, dtype=torch.uint8, device=device)
+                rc = lib.tri_sum_threshold_flagger_debug(
+                    v.data_ptr(), code, f8.data_ptr(), out.data_ptr(), n_cp, ntime,
+                    nchan, C.byref(p), ws.data_ptr(), ws.numel(), stream,
+                    dbg_f.data_ptr(), dbg_u.data_ptr())
+                if rc == 0:
+                    torch.cuda.synchronize(device)
+                    df, du = dbg_f.cpu().numpy(), dbg_u.cpu().numpy()
+                    _debug.update(
+                        spec_resid=df[:fa].copy(),
+                        background=df[fa:fa + n].reshape(fa, ntime).T.copy(),
+                        residual=df[fa + n:].reshape(ntime, fa).copy(),
+                        spec_flags=du[:fa].astype(bool),
+                        time_flags=du[fa:fa + n].reshape(ntime, fa).astype(bool),
+                        freq_flags=du[fa + n:].reshape(ntime, fa).astype(bool))
+            _lib.check(rc)
+        elif ntime <= 0 or nchan <= 0:
+            _lib.check(lib.tri_sum_threshold_flagger(
+                v.data_ptr(), code, f8.data_ptr(), out.data_ptr(), n_cp, ntime, nchan,
+                C.byref(p), None, 0, None))
+    out = out.view(torch.bool)
+    if from_numpy:
+        return out.cpu().numpy()
+    return out
