@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mvis/s flagged by sum_threshold_flagger on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE sum_threshold_flagger call over one HBM-resident slab of the
+MeerKAT-64 configuration (BASELINE.json configs[1]: 2016 bl x 4 corr x 1024
+time x 4096 chan).  The full window set (270.6 GB of complex64 + 33.8 GB of
+flags) exceeds 288 GB of HBM, so it is processed as baseline slabs; every rank
+holds one slab of --bl baselines (weak scaling: with the default 252 baselines
+per rank, 8 ranks together hold exactly the 2016-baseline configuration =
+configs[2]).  Baselines are independent (flagging.py:765-774), so there is no
+data-path collective: ranks only meet at the timing barriers.
+
+Prints ONE JSON line (rank 0): metric/value = whole-job Mvis/s with inputs
+already resident in HBM, plus
+  "roofline"      the fused SumThreshold column kernel, timed live with HIP
+                  events on its launch stream (tri_bench_sumthreshold);
+  "cpu_baseline"  the CPU oracle (a C restatement of the reference's numba
+                  path -- numba itself cannot run here) on a bounded sample of
+                  the same workload on this box's host cores (rank 0, N=1).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PARAM_SETS = {
+    # library defaults (flagging.py:1076-1083)
+    "defaults": dict(),
+    # conf/default.yaml:20-35 "background_flags" -- the heaviest shipped stage
+    "stage1": dict(outlier_nsigma=10, windows_time=[1, 2, 4, 8], windows_freq=[1, 2, 4, 8],
+                   background_reject=2.0, background_iterations=5, spike_width_time=12.5,
+                   spike_width_freq=10.0, time_extend=3, freq_extend=3, freq_chunks=10,
+                   average_freq=1, flag_all_time_frac=0.6, flag_all_freq_frac=0.8, rho=1.3,
+                   num_major_iterations=5),
+    # conf/default.yaml:59-73 "final_st_very_broad"
+    "very_broad": dict(outlier_nsigma=10, windows_time=[1, 2, 4, 8],
+                       windows_freq=[32, 48, 64, 128], background_reject=2.0,
+                       background_iterations=5, spike_width_time=6.5, spike_width_freq=64.0,
+                       time_extend=3, freq_extend=3, freq_chunks=10, average_freq=1,
+                       flag_all_time_frac=0.6, flag_all_freq_frac=0.8, rho=1.3,
+                       num_major_iterations=1),
+}
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+ST_BYTES_PER_SAMPLE = 5  # fused SumThreshold pass: 4 B residual in + 1 B flag out
+
+
+def synth_slab(torch, nbl, ncorr, T, F, device, seed):
+    """SURVEY.md 8(d) synthetic inputs, generated on the device in pieces:
+    complex Gaussian noise (sigma 1) plus deterministic RFI; 2 % of channels
+    pre-flagged; 1e-5 NaN samples."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    vis = torch.empty((nbl, ncorr, T, F), dtype=torch.complex64, device=device)
+    flags = torch.zeros((nbl, ncorr, T, F), dtype=torch.bool, device=device)
+    bad_chan = torch.randperm(F, generator=g, device=device)[: max(1, F // 100)]
+    bad_time = torch.randperm(T, generator=g, device=device)[: max(1, T // 200)]
+    pre_chan = torch.randperm(F, generator=g, device=device)[: max(1, F // 50)]
+    blk0 = int(F * 0.6)
+    for b in range(nbl):
+        re = torch.randn((ncorr, T, F), generator=g, device=device)
+        im = torch.randn((ncorr, T, F), generator=g, device=device)
+        re[:, :, bad_chan] += 8.0
+        re[:, bad_time, :] += 6.0
+        re[:, :, blk0:blk0 + 20] += 3.0
+        n = ncorr * T * F
+        nspike = max(1, n // 10000)
+        idx = torch.randint(0, n, (nspike,), generator=g, device=device)
+        re.view(-1)[idx] += 50.0
+        nnan = max(1, n // 100000)
+        idx = torch.randint(0, n, (nnan,), generator=g, device=device)
+        re.view(-1)[idx] = float("nan")
+        vis[b] = torch.complex(re, im)
+        del re, im
+    flags[:, :, :, pre_chan] = True
+    return vis, flags
+
+
+def cpu_baseline(kw, T, F, seconds_budget=25.0):
+    """Oracle (C restatement of the reference CPU path, OpenMP over windows)
+    on a bounded sample of the same workload."""
+    from oracle import oracle
+    oracle.set_modes(oracle.POW_SQMUL, oracle.INTERP_F64)
+    cores = min(os.cpu_count() or 1, 16)
+    rs = np.random.RandomState(1234)
+
+    def make(nwin):
+        vis = (rs.standard_normal((nwin, 1, T, F)) + 1j * rs.standard_normal((nwin, 1, T, F))).astype(np.complex64)
+        vis.real[..., ::97] += 8.0
+        vis.real[:, :, ::211, :] += 6.0
+        flags = np.zeros(vis.shape, np.bool_)
+        flags[..., ::50] = True
+        return vis, flags
+
+    # calibrate on one window with one thread, then size the sample
+    vis, flags = make(1)
+    t0 = time.time()
+    oracle.sum_threshold_flagger(vis, flags, n_threads=1, **kw)
+    t1 = time.time() - t0
+    per_thread = max(1, int(seconds_budget / max(t1, 1e-3)))
+    nwin = cores * min(per_thread, 2)
+    if t1 > seconds_budget:
+        nwin = cores
+    vis, flags = make(nwin)
+    t0 = time.time()
+    oracle.sum_threshold_flagger(vis, flags, n_threads=cores, **kw)
+    dt = time.time() - t0
+    return dict(value=round(nwin * T * F / dt / 1e6, 3), unit="Mvis/s", cores=cores, kind="port",
+                sample="%d windows of %dx%d (1 corr), same kwargs, %.1f s; C restatement of the "
+                       "reference numba path (oracle/), OpenMP over windows" % (nwin, T, F, dt))
+
+
+def roofline_sumthreshold(torch, device, T, F, kw):
+    """Times the fused SumThreshold column kernel alone (time-axis geometry:
+    line = time, coalesced columns = channels) with HIP events on its stream."""
+    from tricolour_amd import _lib
+    lib = _lib.lib()
+    nwin = 64
+    g = torch.Generator(device=device)
+    g.manual_seed(7)
+    data = torch.randn((nwin, T, F), generator=g, device=device)
+    data[:, :, ::101] += 9.0
+    mad = torch.full((nwin, F), 0.6745, dtype=torch.float64, device=device)
+    out = torch.empty((nwin, T, F), dtype=torch.uint8, device=device)
+    wins = kw.get("windows_time", [1, 2, 4, 8])
+    warr = (C.c_int64 * len(wins))(*[int(w) for w in wins])
+    ms = C.c_float(0)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    for reps in (2, 10):
+        _lib.check(lib.tri_bench_sumthreshold(data.data_ptr(), mad.data_ptr(), out.data_ptr(),
+                                              nwin, T, F, warr, len(wins),
+                                              float(kw.get("outlier_nsigma", 4.5)),
+                                              float(kw.get("rho", 1.3)), 0, reps,
+                                              C.byref(ms), stream))
+    samples = nwin * T * F
+    achieved = samples * ST_BYTES_PER_SAMPLE / (ms.value * 1e-3) / 1e9
+    return dict(bound="hbm", kernel="k_colst (fused SumThreshold, all windows in one pass)",
+                achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                bytes_per_sample=ST_BYTES_PER_SAMPLE, samples_per_launch=samples,
+                ms_per_launch=round(ms.value, 4))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--bl", type=int, default=int(os.environ.get("TRI_BENCH_BL", "252")),
+                    help="baselines per rank (slab of the 2016-baseline configuration)")
+    ap.add_argument("--corr", type=int, default=4)
+    ap.add_argument("--time", type=int, default=1024)
+    ap.add_argument("--chan", type=int, default=4096)
+    ap.add_argument("--params", choices=sorted(PARAM_SETS), default="defaults")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import tricolour_amd
+    from tricolour_amd import flagging
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    device = torch.device("cuda", torch.cuda.current_device())
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+
+    kw = PARAM_SETS[args.params]
+    T, F = args.time, args.chan
+    vis, flags = synth_slab(torch, args.bl, args.corr, T, F, device, 1234 + rank)
+    torch.cuda.synchronize()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out = None
+    for _ in range(args.warmup):
+        out = tricolour_amd.sum_threshold_flagger(vis, flags, **kw)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = tricolour_amd.sum_threshold_flagger(vis, flags, **kw)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    flagged = float(out.float().mean().item()) if out is not None else float("nan")
+    nvis_rank = args.bl * args.corr * T * F
+    total_vis = nvis_rank * world * args.steps
+    value = total_vis / dt / 1e6
+
+    if rank == 0:
+        res = {
+            "metric": "Mvis/s flagged (bl x time x chan x corr)",
+            "value": round(value, 2),
+            "unit": "Mvis/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32 data / f64 accumulators / u8 flags",
+            "data": "synthetic",
+            "config": {
+                "workload": "MeerKAT-64 slab: %d of 2016 bl x %d corr x %d time x %d chan per GPU "
+                            "(BASELINE configs[1] processed as HBM-resident baseline slabs), "
+                            "sum_threshold_flagger kwargs=%s" % (args.bl, args.corr, T, F, args.params),
+                "baselines_per_gpu": args.bl,
+                "params": args.params,
+                "sharding": "baselines across ranks, no data-path collective",
+                "flagged_fraction": round(flagged, 4),
+            },
+        }
+        del vis, flags, out
+        flagging.release_workspace()
+        torch.cuda.empty_cache()
+        if not args.no_roofline:
+            res["roofline"] = roofline_sumthreshold(torch, device, T, F, kw)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(kw, T, F)
+        print(json.dumps(res))
+        sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

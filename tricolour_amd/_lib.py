@@ -119,6 +119,11 @@ def lib():
                 "tricolour_amd: HIP extension %s is missing -- run "
                 "`python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback)" % LIB_PATH)
+        # PyTorch owns the process's HIP runtime (its wheel bundles
+        # libamdhip64.so.7).  Import it first so that the extension's
+        # NEEDED libamdhip64.so.7 binds to that same runtime instance --
+        # device pointers and streams are only meaningful within one.
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)

@@ -177,7 +177,6 @@ def sum_threshold_flagger(vis, flags, outlier_nsigma=4.5,
     Returns the flags found by the LAST major iteration (not OR-ed with the
     input flags), bool, same 4-D shape; inputs are never modified.
     """
-    torch = _require_gpu()
     lib = _lib.lib()
     if tuple(vis.shape) != tuple(flags.shape):
         raise ValueError("shape mismatch")           # flagging.py:840-841
@@ -190,6 +189,7 @@ def sum_threshold_flagger(vis, flags, outlier_nsigma=4.5,
                        spike_width_freq, time_extend, freq_extend, freq_chunks,
                        average_freq, flag_all_time_frac, flag_all_freq_frac, rho,
                        num_major_iterations)
+    torch = _require_gpu()
     v, f8, code, from_numpy, device = _as_device_inputs(torch, vis, flags)
     if code == -64:
         if int(average_freq) != 1:
