@@ -111,3 +111,46 @@ def test_inputs_not_modified_and_torch_roundtrip(gpu, oracle):
     assert torch.equal(vt, v0) and torch.equal(ft, f0)
     exp = oracle.sum_threshold_flagger(amp, flags, num_major_iterations=1)
     assert np.array_equal(out.cpu().numpy(), exp)
+
+
+def _run_st_kernel(data, mad, windows, nsigma, rho, variant):
+    import ctypes as C
+    import torch
+    from tricolour_amd import _lib
+    d = torch.from_numpy(np.ascontiguousarray(data, np.float32)).cuda()
+    m = torch.from_numpy(np.ascontiguousarray(mad, np.float64)).cuda()
+    out = torch.full(d.shape, 7, dtype=torch.uint8, device="cuda")
+    warr = (C.c_int64 * len(windows))(*windows)
+    ms = C.c_float(0)
+    n_win, n_line, n_col = d.shape
+    _lib.check(_lib.lib().tri_bench_sumthreshold(d.data_ptr(), m.data_ptr(), out.data_ptr(), n_win,
+                                                 n_line, n_col, warr, len(windows), nsigma, rho,
+                                                 variant, 1, C.byref(ms), None))
+    torch.cuda.synchronize()
+    return out.cpu().numpy().astype(bool)
+
+
+@pytest.mark.parametrize("shape", [(2, 200, 70), (1, 5, 300), (3, 1024, 130), (1, 17, 64), (2, 33, 257)])
+def test_fused_sumthreshold_kernel_vs_generic_and_oracle(gpu, oracle, shape):
+    """The register cascade (windows 1,2,4,8) against the generic kernel and
+    against the oracle's _sum_threshold along axis 0, including lines without
+    any unflagged sample (NaN MAD -> infinite threshold) and short lines."""
+    rs = np.random.RandomState(shape[1])
+    data = rs.standard_normal(shape).astype(np.float32) * 2.0
+    data[:, shape[1] // 3, :] += 30.0
+    data[:, :, 5] -= 25.0
+    data[0, -1, :] += 40.0        # hit at the very end of the line
+    data[0, 0, :3] -= 40.0        # and at the very start
+    flags = rs.uniform(size=shape) < 0.1
+    flags[:, :, 7] = True         # a fully flagged line
+    windows = [w for w in (1, 2, 4, 8) if w <= shape[1]]
+    mad = np.empty((shape[0], shape[2]), np.float64)
+    for w in range(shape[0]):
+        mad[w] = oracle.median_abs_axis0(data[w], flags[w]).astype(np.float64).reshape(-1)
+    gen = _run_st_kernel(data, mad, windows, 4.5, 1.3, 1)
+    for w in range(shape[0]):
+        exp = oracle.sum_threshold(data[w], flags[w], 0, np.array(windows), 4.5, 1.3)
+        assert np.array_equal(gen[w], exp), "generic kernel, window %d" % w
+    if windows == [1, 2, 4, 8]:
+        fused = _run_st_kernel(data, mad, windows, 4.5, 1.3, 2)
+        assert np.array_equal(fused, gen)

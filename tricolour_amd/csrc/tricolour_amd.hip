@@ -23,7 +23,9 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/tricolour_amd.h"
@@ -655,6 +657,161 @@ k_colst_dyn(const float* __restrict__ data, const double* __restrict__ med,
 }
 
 // ---------------------------------------------------------------------------
+// K7b  Register-resident SumThreshold cascade for power-of-two windows
+// {W0,W1,W2,W3} with W3 <= 8 (the library default and every shipped strategy's
+// time axis: 1,2,4,8).  Same arithmetic as k_colst_dyn, but
+//   * the prefix rings (w doubles per stage), the 8-deep sample ring and the
+//     hit / input-flag histories (bit shift registers) live in VGPRs: the tick
+//     loop is unrolled by 8 so that every ring index is a compile-time
+//     constant;
+//   * stage j+1 runs w_j positions behind stage j (one more than necessary),
+//     so the flag hand-off crosses a tick boundary and the four stages of one
+//     tick are independent instruction streams;
+//   * for a power-of-two window, S * f32(1/w) > thr  <=>  S > thr * w exactly
+//     (both sides scale by 2^k; S is a multiple of 2^-203 or larger, far above
+//     the underflow range), so the threshold tests need no multiply.
+// One thread per (column, chunk); HBM traffic = 4 B in + 1 B out per sample.
+// grid (ceil(C/BLK), G, W), block BLK
+// ---------------------------------------------------------------------------
+struct StFusedArgs {
+    double tf[4];   // rho ** log2(w)
+};
+
+template <int W0, int W1, int W2, int W3>
+__global__ void __launch_bounds__(256)
+k_colst_fused(const float* __restrict__ data, const double* __restrict__ med,
+              uint8_t* __restrict__ out, const int64_t* __restrict__ chunk_ends,
+              StFusedArgs fa, double thr_scale, int L, int C, int G, size_t ws_data,
+              size_t ws_out) {
+    constexpr int W[4] = {W0, W1, W2, W3};
+    constexpr int D[4] = {0, W0, W0 + W1, W0 + W1 + W2};   // ingest delay of stage j
+    constexpr int DOUT = W0 + W1 + W2 + W3 - 1;             // final flags lag the head by this
+    constexpr int MAXW = W3;
+    static_assert(W0 <= W1 && W1 <= W2 && W2 <= W3 && W3 <= 8, "windows must be sorted, <= 8");
+    static_assert((W0 & (W0 - 1)) == 0 && (W1 & (W1 - 1)) == 0 && (W2 & (W2 - 1)) == 0 &&
+                  (W3 & (W3 - 1)) == 0, "power-of-two windows");
+    static_assert(W0 + W1 + W2 <= 7, "sample ring is 8 deep");
+
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int g = blockIdx.y;
+    const size_t win = blockIdx.z;
+    const int c0 = (int)chunk_ends[g], c1 = (int)chunk_ends[g + 1];
+    if (c1 <= c0) return;
+    const float* x = data + win * ws_data + c;
+    uint8_t* o = out + win * ws_out + c;
+    const size_t Cs = (size_t)C;
+
+    float mad = (float)med[(win * (size_t)C + c) * G + g];
+    float thr0 = isnan(mad) ? INFINITY : (float)((double)mad * thr_scale);
+    const int p0 = max(c0 - MAXW + 1, 0);
+    const int p1 = min(c1 + MAXW - 1, L);
+    const int Lp = p1 - p0;
+    const int o0 = c0 - p0, o1 = c1 - p0;   // output interior in padded coordinates
+    x += (size_t)p0 * Cs;
+    o += (size_t)p0 * Cs;
+
+    double thr[4], T[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        thr[j] = (double)thr0 / fa.tf[j];
+        T[j] = thr[j] * (double)W[j];
+    }
+    double cumlast[4] = {0.0, 0.0, 0.0, 0.0};
+    double r0[W0], r1[W1], r2[W2], r3[W3];
+#pragma unroll
+    for (int k = 0; k < W0; k++) r0[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < W1; k++) r1[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < W2; k++) r2[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < W3; k++) r3[k] = 0.0;
+    unsigned hb[4] = {0, 0, 0, 0}, inb[4] = {0, 0, 0, 0};
+    unsigned hand[4] = {0, 0, 0, 0};   // flags emitted by stage j at the previous tick (bit0 pos, bit16 neg)
+    double xr[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) xr[k] = 0.0;
+
+    const int nticks = Lp + DOUT;
+    float cur[8], nxt[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) cur[u] = (u < Lp) ? x[(size_t)u * Cs] : 0.0f;
+
+    auto block = [&](auto fastc, const int base) {
+        constexpr bool fast = decltype(fastc)::value;
+#pragma unroll
+        for (int PH = 0; PH < 8; PH++) {
+            const int n = base + PH;
+            xr[PH] = (double)cur[PH];
+            unsigned outbits = 0;
+            // stages in reverse order: stage j consumes the hand-off of stage
+            // j-1 written at the previous tick before stage j-1 overwrites it
+#pragma unroll
+            for (int j = 3; j >= 0; j--) {
+                const int w = W[j];
+                const int i = n - D[j];
+                const int e = i + 1 - w;
+                const unsigned fin = (j == 0) ? 0u : hand[j - 1];
+                const bool ing = fast || (i >= 0 && i < Lp);
+                const bool emi = fast || (e >= 0 && e < Lp);
+                bool hp = false, hn = false;
+                if (ing) {
+                    double xd = xr[(PH - D[j]) & 7];
+                    double cl = xd;
+                    if ((fin & 1u) && xd > thr[j]) cl = thr[j];
+                    else if ((fin & 0x10000u) && xd < -thr[j]) cl = -thr[j];
+                    double cum = cumlast[j] + cl;
+                    cumlast[j] = cum;
+                    const int slot = (PH - D[j] + 1) & (w - 1);
+                    double old;
+                    if (j == 0) { old = r0[slot & (W0 - 1)]; r0[slot & (W0 - 1)] = cum; }
+                    else if (j == 1) { old = r1[slot & (W1 - 1)]; r1[slot & (W1 - 1)] = cum; }
+                    else if (j == 2) { old = r2[slot & (W2 - 1)]; r2[slot & (W2 - 1)] = cum; }
+                    else { old = r3[slot & (W3 - 1)]; r3[slot & (W3 - 1)] = cum; }
+                    if (fast || e >= 0) {
+                        double S = cum - old;
+                        hp = S > T[j];
+                        hn = S < -T[j];
+                    }
+                }
+                // both histories keep w bits per sign (pos in bits 0.., neg in
+                // bits 16..); the mask stops old pos bits leaking into the neg field
+                const unsigned m = (1u << w) - 1u;
+                const unsigned m2 = m | (m << 16);
+                if (emi) {
+                    hb[j] = ((hb[j] << 1) & m2) | (hp ? 1u : 0u) | (hn ? 0x10000u : 0u);
+                    inb[j] = ((inb[j] << 1) & m2) | (ing ? (fin & 0x10001u) : 0u);
+                    unsigned pout = ((inb[j] >> (w - 1)) & 1u) | ((hb[j] & m) ? 1u : 0u);
+                    unsigned nout = ((inb[j] >> (16 + w - 1)) & 1u) | ((hb[j] & (m << 16)) ? 1u : 0u);
+                    hand[j] = pout | (nout << 16);
+                    if (j == 3) outbits = pout | nout;
+                } else if (ing) {
+                    // positions before the first emit: keep the input-flag history moving
+                    inb[j] = ((inb[j] << 1) & m2) | (fin & 0x10001u);
+                }
+            }
+            const int ef = n - DOUT;
+            if (fast || (ef >= o0 && ef < o1)) o[(size_t)ef * Cs] = (uint8_t)outbits;
+        }
+    };
+
+    for (int base = 0; base < nticks; base += 8) {
+        // prefetch the next block of samples
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            int n = base + 8 + u;
+            nxt[u] = (n < Lp) ? x[(size_t)n * Cs] : 0.0f;
+        }
+        const bool fast = base >= 16 && base + 7 < Lp && base - DOUT >= o0 && base + 7 - DOUT < o1;
+        if (fast) block(std::true_type{}, base);
+        else block(std::false_type{}, base);
+#pragma unroll
+        for (int u = 0; u < 8; u++) cur[u] = nxt[u];
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K8  _combine_flags + _unaverage_freq (flagging.py:784-918), TF layout.
 // comb[t][fa] = any over t' in [t - e/2, t - e/2 + e) of (spec|time|freq).
 // ---------------------------------------------------------------------------
@@ -1064,6 +1221,17 @@ struct Run {
     Debug* dbg;      // taps of window 0 (tests only), or NULL
 };
 
+// The register cascade covers windows exactly (1,2,4,8) in that order; the
+// environment variable TRI_ST_GENERIC=1 forces the generic kernel (tests).
+bool st_use_fused(const StWin& sw) {
+    static const bool force_generic = [] {
+        const char* e = getenv("TRI_ST_GENERIC");
+        return e && e[0] == '1';
+    }();
+    if (force_generic) return false;
+    return sw.nw == 4 && sw.w[0] == 1 && sw.w[1] == 2 && sw.w[2] == 4 && sw.w[3] == 8;
+}
+
 int launch_median(const Run& r, const float* data, const uint8_t* flags, double* med, size_t WSd,
                   size_t WSf, size_t RS, size_t ES, const int64_t* seg_start,
                   const int64_t* seg_len, int R, int G, int64_t W) {
@@ -1097,8 +1265,15 @@ int launch_colst(const Run& r, const StWin& sw, const float* data, const double*
     double thr_scale = r.p->outlier_nsigma * TRI_MAD_NORMAL;  // flagging.py:623
     int blk = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
     dim3 grid((unsigned)cdiv(C, blk), (unsigned)G, (unsigned)W);
-    hipLaunchKernelGGL(k_colst_dyn, grid, dim3(blk), 0, r.st, data, med, out, r.ws.ring, r.ws.acc,
-                       d_chunk_ends, sw, thr_scale, L, C, G, ws_data, ws_out);
+    if (st_use_fused(sw)) {
+        StFusedArgs fa;
+        for (int j = 0; j < 4; j++) fa.tf[j] = sw.tf[j];
+        hipLaunchKernelGGL((k_colst_fused<1, 2, 4, 8>), grid, dim3(blk), 0, r.st, data, med, out,
+                           d_chunk_ends, fa, thr_scale, L, C, G, ws_data, ws_out);
+    } else {
+        hipLaunchKernelGGL(k_colst_dyn, grid, dim3(blk), 0, r.st, data, med, out, r.ws.ring, r.ws.acc,
+                           d_chunk_ends, sw, thr_scale, L, C, G, ws_data, ws_out);
+    }
     LAUNCHCHK();
     return TRI_OK;
 }
@@ -1495,10 +1670,17 @@ extern "C" int tri_bench_sumthreshold(const float* data, const double* mad, uint
     int blk = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
     dim3 grid((unsigned)cdiv(C, blk), 1, (unsigned)n_win);
     size_t ws = (size_t)n_line * n_col;
-    (void)variant;
+    bool can_fuse = sw.nw == 4 && sw.w[0] == 1 && sw.w[1] == 2 && sw.w[2] == 4 && sw.w[3] == 8;
+    if (variant == 2 && !can_fuse) return set_err(TRI_EUNSUPPORTED, "register cascade needs windows (1,2,4,8)");
+    bool fused = variant == 2 || (variant == 0 && can_fuse);
+    StFusedArgs fa;
+    for (int j = 0; j < 4; j++) fa.tf[j] = sw.tf[j < sw.nw ? j : 0];
     HIPCHK(hipEventRecord(e0, st));
     for (int i = 0; i < repeats; i++) {
-        hipLaunchKernelGGL(k_colst_dyn, grid, dim3(blk), 0, st, data, mad, out, ring, acc, d_ends, sw, thr_scale, L, C, 1, ws, ws);
+        if (fused)
+            hipLaunchKernelGGL((k_colst_fused<1, 2, 4, 8>), grid, dim3(blk), 0, st, data, mad, out, d_ends, fa, thr_scale, L, C, 1, ws, ws);
+        else
+            hipLaunchKernelGGL(k_colst_dyn, grid, dim3(blk), 0, st, data, mad, out, ring, acc, d_ends, sw, thr_scale, L, C, 1, ws, ws);
     }
     HIPCHK(hipEventRecord(e1, st));
     HIPCHK(hipEventSynchronize(e1));
