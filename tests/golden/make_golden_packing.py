@@ -58,7 +58,6 @@ def pack_unpack(name, rs, na, ntime, nchan, ncorr, delete_frac, row_chunks, bl_c
     ant1, ant2, tm, data, flag = make_rows(rs, na, ntime, nchan, ncorr, delete_frac, flagger_kw is not None)
     if flagger_kw is not None:
         data[:, nchan // 3, :] += 9.0
-        data[::17, :, :] += 6.0
     d_ant1 = da.from_array(ant1, chunks=row_chunks)
     d_ant2 = da.from_array(ant2, chunks=row_chunks)
     d_data = da.from_array(data, chunks=(row_chunks, nchan, ncorr))

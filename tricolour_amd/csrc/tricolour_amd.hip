@@ -423,6 +423,136 @@ k_colfilter(float* __restrict__ bufW, float* __restrict__ bufO,
     }
 }
 
+// ---------------------------------------------------------------------------
+// K4b  Single-sweep variant of the box filter for moderate radii: the four
+// passes run as a cascade of causal running sums in ONE pass over the line
+// (HBM traffic: one read and one write per image sample), with each stage's
+// 2r-deep delay line in LDS ([stage][slot][thread], conflict-free).
+//
+// Equivalence with the in-place passes of flagging.py:394-417 (t = causal
+// index, in_p = input stream of pass p, zero where the reference's padded
+// array holds padding or was never written):
+//     s_p += in_p[t];  out_p[t] = f32(s_p);  s_p -= in_p[t - 2r]
+// with in_1 = data (t in [0,n)), in_2 = out_1 (t in [0,n+2r)), in_3 = out_2
+// (t in [0,n+4r)), in_4 = out_3 restricted to t >= 2r (the reference never
+// forms padded_3 below index 0), result y[i] = out_4[i + 4r] / f32(d)**4.
+// Adding / subtracting the synthesised zeros is exact, so every float64
+// value equals the reference's.  Stage p+1 runs one step behind stage p so
+// the four float64 chains of a step are independent.
+// grid (ceil(C/BT), W, 2 images), block BT, dynamic LDS 4 * 2r * BT floats
+// ---------------------------------------------------------------------------
+template <int SRCMODE>
+__global__ void __launch_bounds__(256)
+k_colfilter_lds(const float* __restrict__ srcW, const float* __restrict__ srcO,
+                const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags,
+                float* __restrict__ dstW, float* __restrict__ dstO,
+                int n, int C, int r, float denom, size_t sws_img, size_t sws, size_t dws) {
+    extern __shared__ float cf_ring[];
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const size_t win = blockIdx.y;
+    const int img = blockIdx.z;
+    const int BT = blockDim.x;
+    const int R2 = 2 * r;
+    const size_t Cs = (size_t)C;
+    const float* src = SRCMODE == 1 ? ((img == 0 ? srcW : srcO) + win * sws_img + c) : nullptr;
+    const float* sd = SRCMODE == 0 ? srcData + win * sws + c : nullptr;
+    const uint8_t* sf = SRCMODE == 0 ? srcFlags + win * sws + c : nullptr;
+    float* dst = (img == 0 ? dstW : dstO) + win * dws + c;
+    float* ring = cf_ring + threadIdx.x;            // element (p, slot) at ((p*R2)+slot)*BT
+    for (int k = 0; k < 4 * R2; k++) ring[(size_t)k * BT] = 0.0f;
+
+    auto load = [&](int t) -> float {
+        if (SRCMODE == 0) {
+            bool fl = sf[(size_t)t * Cs] != 0;
+            if (img == 0) return fl ? 0.0f : 1.0f;
+            return fl ? 0.0f : sd[(size_t)t * Cs];
+        }
+        return src[(size_t)t * Cs];
+    };
+
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0;
+    float o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;       // stage outputs of the previous step
+    int slot1 = 0, slot2 = 0, slot3 = 0, slot4 = 0;
+    const int total = n + 4 * r + 3;
+    constexpr int PF = 8;
+    float pre[PF];
+#pragma unroll
+    for (int u = 0; u < PF; u++) pre[u] = (u < n) ? load(u) : 0.0f;
+    for (int m0 = 0; m0 < total; m0 += PF) {
+        float cur[PF];
+#pragma unroll
+        for (int u = 0; u < PF; u++) cur[u] = pre[u];
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            int t = m0 + PF + u;
+            pre[u] = (t < n) ? load(t) : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int m = m0 + u;
+            // stage 4 (time t4 = m - 3): input out_3[t4], present for 2r <= t4 < n + 4r
+            {
+                const int t = m - 3;
+                if (t >= 0 && t < n + 4 * r) {
+                    float in = (t >= R2) ? o3 : 0.0f;
+                    float* rp = ring + (size_t)(3 * R2 + slot4) * BT;
+                    float old = *rp;
+                    *rp = in;
+                    if (++slot4 == R2) slot4 = 0;
+                    s4 += (double)in;
+                    float out = (float)s4;
+                    s4 -= (double)old;
+                    int i = t - 4 * r;
+                    if (i >= 0) dst[(size_t)i * Cs] = out / denom;
+                }
+            }
+            // stage 3 (t3 = m - 2): input out_2[t3], t3 in [0, n + 4r)
+            {
+                const int t = m - 2;
+                if (t >= 0 && t < n + 4 * r) {
+                    float in = o2;
+                    float* rp = ring + (size_t)(2 * R2 + slot3) * BT;
+                    float old = *rp;
+                    *rp = in;
+                    if (++slot3 == R2) slot3 = 0;
+                    s3 += (double)in;
+                    o3 = (float)s3;
+                    s3 -= (double)old;
+                }
+            }
+            // stage 2 (t2 = m - 1): input out_1[t2] for t2 < n + 2r, then drains to n + 4r
+            {
+                const int t = m - 1;
+                if (t >= 0 && t < n + 4 * r) {
+                    float in = (t < n + R2) ? o1 : 0.0f;
+                    float* rp = ring + (size_t)(1 * R2 + slot2) * BT;
+                    float old = *rp;
+                    *rp = in;
+                    if (++slot2 == R2) slot2 = 0;
+                    s2 += (double)in;
+                    o2 = (float)s2;
+                    s2 -= (double)old;
+                }
+            }
+            // stage 1 (t1 = m): input data[t1] for t1 < n, drains to n + 2r
+            {
+                const int t = m;
+                if (t < n + R2) {
+                    float in = (t < n) ? cur[u] : 0.0f;
+                    float* rp = ring + (size_t)slot1 * BT;
+                    float old = *rp;
+                    *rp = in;
+                    if (++slot1 == R2) slot1 = 0;
+                    s1 += (double)in;
+                    o1 = (float)s1;
+                    s1 -= (double)old;
+                }
+            }
+        }
+    }
+}
+
 // r == 0 on both axes: weight = !flag, data = flag ? 0 : x (flagging.py:500-503
 // followed by the plain copy of flagging.py:465-466).
 __global__ void k_build_wo(const float* __restrict__ data, const uint8_t* __restrict__ flags,
@@ -878,6 +1008,259 @@ __global__ void k_final(const uint8_t* __restrict__ dil, const int* __restrict__
 }
 
 // ---------------------------------------------------------------------------
+// Vectorised (16 bytes of flags / 4 floats per thread) forms of the
+// elementwise kernels above, used when the row lengths are multiples of 16
+// (every production shape); the scalar kernels remain the general fallback.
+// Flags are 0/1 bytes, so byte-wise OR is a plain bitwise OR of the words.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint4 or4(uint4 a, uint4 b) { return make_uint4(a.x | b.x, a.y | b.y, a.z | b.z, a.w | b.w); }
+// per byte: x != 0 ? 1 : 0 (no cross-byte carries)
+__device__ __forceinline__ unsigned nz_bytes(unsigned x) {
+    unsigned t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    return ((t | x) & 0x80808080u) >> 7;
+}
+
+template <int VD>
+__global__ void k_prepare4(const void* __restrict__ vis, const uint8_t* __restrict__ iflags,
+                           float* __restrict__ data, uint8_t* __restrict__ flags, size_t n4) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // group of 4 samples, flat over the batch
+    if (i >= n4) return;
+    uchar4 f = reinterpret_cast<const uchar4*>(iflags)[i];
+    float a[4];
+    if (VD == TRI_VIS_C64) {
+        float4 z0 = reinterpret_cast<const float4*>(vis)[2 * i];
+        float4 z1 = reinterpret_cast<const float4*>(vis)[2 * i + 1];
+        a[0] = tri_hypotf(z0.x, z0.y); a[1] = tri_hypotf(z0.z, z0.w);
+        a[2] = tri_hypotf(z1.x, z1.y); a[3] = tri_hypotf(z1.z, z1.w);
+    } else {
+        float4 z = reinterpret_cast<const float4*>(vis)[i];
+        a[0] = fabsf(z.x); a[1] = fabsf(z.y); a[2] = fabsf(z.z); a[3] = fabsf(z.w);
+    }
+    unsigned char fl[4] = {f.x, f.y, f.z, f.w};
+    float o[4];
+    unsigned char of[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        bool bad = fl[k] != 0 || isnan(a[k]);
+        // factor 1: sum = 0 + a, count 1, a / 1.0f = a (flagging.py:858-870)
+        o[k] = bad ? 0.0f : (0.0f + a[k]) / 1.0f;
+        of[k] = bad ? 1 : 0;
+    }
+    reinterpret_cast<float4*>(data)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    reinterpret_cast<uchar4*>(flags)[i] = make_uchar4(of[0], of[1], of[2], of[3]);
+}
+
+// OP 0: b = a   OP 1: b |= a   OP 2: b = (a != 0)     (16 bytes per thread)
+template <int OP>
+__global__ void k_u8_op16(const uint8_t* __restrict__ a, uint8_t* __restrict__ b, size_t n16per,
+                          size_t ws_a, size_t ws_b) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n16per) return;
+    size_t win = blockIdx.y;
+    uint4 va = reinterpret_cast<const uint4*>(a + win * ws_a)[i];
+    uint4* pb = reinterpret_cast<uint4*>(b + win * ws_b) + i;
+    if (OP == 0) *pb = va;
+    else if (OP == 1) *pb = or4(*pb, va);
+    else *pb = make_uint4(nz_bytes(va.x), nz_bytes(va.y), nz_bytes(va.z), nz_bytes(va.w));
+}
+
+// spectrum flags [Fa][Wn] -> rows [Wn][Fa] (tiny), so that the per-window
+// kernels below can read 16 channels at a time
+__global__ void k_spec_rows(const uint8_t* __restrict__ spec, uint8_t* __restrict__ rows, int Fa, int Wn) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)Fa * Wn) return;
+    int w = (int)(i / Fa), f = (int)(i % Fa);
+    rows[i] = spec[(size_t)f * Wn + w];
+}
+
+// flags[w][t][f..f+15] |= spec_rows[w][f..f+15]
+__global__ void k_or_spec16(uint8_t* __restrict__ flags, const uint8_t* __restrict__ spec_rows, int T, int Fa16) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)T * Fa16) return;
+    size_t win = blockIdx.y;
+    int f16 = (int)(i % Fa16);
+    uint4 sp = reinterpret_cast<const uint4*>(spec_rows + win * (size_t)Fa16 * 16)[f16];
+    uint4* pf = reinterpret_cast<uint4*>(flags + win * (size_t)T * Fa16 * 16) + i;
+    *pf = or4(*pf, sp);
+}
+
+// _combine_flags (flagging.py:784-816), 16 channels per thread
+__global__ void k_combine16(const uint8_t* __restrict__ spec_rows, const uint8_t* __restrict__ tflags,
+                            const uint8_t* __restrict__ fflags, uint8_t* __restrict__ comb, int T,
+                            int Fa16, int lo, int hi) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)T * Fa16) return;
+    size_t win = blockIdx.y;
+    int t = (int)(i / Fa16), f16 = (int)(i % Fa16);
+    size_t base = win * (size_t)T * Fa16;
+    int t0 = max(t + lo, 0), t1 = min(t + hi, T);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (t1 > t0) {
+        v = reinterpret_cast<const uint4*>(spec_rows + win * (size_t)Fa16 * 16)[f16];
+        const uint4* tp = reinterpret_cast<const uint4*>(tflags) + base;
+        const uint4* fp = reinterpret_cast<const uint4*>(fflags) + base;
+        for (int tt = t0; tt < t1; tt++) {
+            size_t a = (size_t)tt * Fa16 + f16;
+            v = or4(v, or4(tp[a], fp[a]));
+        }
+    }
+    reinterpret_cast<uint4*>(comb)[base + i] = v;
+}
+
+// _unaverage_freq (flagging.py:896-908) for average_freq == 1, frequency
+// dilation over [f + LO, f + LO + E), 16 channels per thread; row counts by
+// popcount + one atomic per wave; column counts by k_colcount.
+// grid (ceil(F16/64), T, W), block 64
+template <int LO, int E>
+__global__ void k_unaverage16(const uint8_t* __restrict__ comb, uint8_t* __restrict__ dil,
+                              int* __restrict__ rowcnt, int T, int F16) {
+    int f16 = blockIdx.x * blockDim.x + threadIdx.x;
+    int t = blockIdx.y;
+    size_t win = blockIdx.z;
+    int cnt = 0;
+    if (f16 < F16) {
+        const uint4* row = reinterpret_cast<const uint4*>(comb) + (win * (size_t)T + t) * F16;
+        uint4 z = make_uint4(0, 0, 0, 0);
+        uint4 p = f16 > 0 ? row[f16 - 1] : z;
+        uint4 c = row[f16];
+        uint4 n = f16 + 1 < F16 ? row[f16 + 1] : z;
+        unsigned w[12] = {p.x, p.y, p.z, p.w, c.x, c.y, c.z, c.w, n.x, n.y, n.z, n.w};
+        unsigned o[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            unsigned v = 0;
+#pragma unroll
+            for (int sft = LO; sft < LO + E; sft++) {
+                const int idx = 16 + k + sft;   // byte index into the 48-byte window
+                v |= (w[idx >> 2] >> (8 * (idx & 3))) & 0xFFu;
+            }
+            o[k >> 2] |= (v & 1u) << (8 * (k & 3));
+        }
+        reinterpret_cast<uint4*>(dil)[(win * (size_t)T + t) * F16 + f16] = make_uint4(o[0], o[1], o[2], o[3]);
+        cnt = __popc(o[0]) + __popc(o[1]) + __popc(o[2]) + __popc(o[3]);
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&rowcnt[win * (size_t)T + t], cnt);
+}
+
+// column counts of a [T][F] 0/1 byte image: one thread per 4 columns
+// grid (ceil(F4/256), W)
+__global__ void k_colcount(const uint8_t* __restrict__ dil, int* __restrict__ colcnt, int T, int F4) {
+    int f4 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f4 >= F4) return;
+    size_t win = blockIdx.y;
+    const unsigned* p = reinterpret_cast<const unsigned*>(dil) + win * (size_t)T * F4 + f4;
+    unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    int t = 0;
+    for (; t + 8 <= T; t += 8) {
+        unsigned v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = p[(size_t)(t + u) * F4];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            c0 += v[u] & 0xFFu; c1 += (v[u] >> 8) & 0xFFu; c2 += (v[u] >> 16) & 0xFFu; c3 += v[u] >> 24;
+        }
+    }
+    for (; t < T; t++) {
+        unsigned v = p[(size_t)t * F4];
+        c0 += v & 0xFFu; c1 += (v >> 8) & 0xFFu; c2 += (v >> 16) & 0xFFu; c3 += v >> 24;
+    }
+    reinterpret_cast<int4*>(colcnt)[win * (size_t)F4 + f4] = make_int4((int)c0, (int)c1, (int)c2, (int)c3);
+}
+
+// k_final, 16 samples per thread
+template <int VD>
+__global__ void k_final16(const uint8_t* __restrict__ dil, const int* __restrict__ rowcnt,
+                          const int* __restrict__ colcnt, const void* __restrict__ vis,
+                          uint8_t* __restrict__ out, uint8_t* __restrict__ iter, int T, int F16,
+                          double row_limit, double col_limit, int update_iter) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)T * F16) return;
+    size_t win = blockIdx.y;
+    int t = (int)(i / F16), f16 = (int)(i % F16);
+    size_t a16 = win * (size_t)T * F16 + i;
+    uint4 d = reinterpret_cast<const uint4*>(dil)[a16];
+    unsigned dw[4] = {d.x, d.y, d.z, d.w};
+    bool rowall = (double)rowcnt[win * (size_t)T + t] > row_limit;
+    const int4* cc = reinterpret_cast<const int4*>(colcnt + win * (size_t)F16 * 16) + (size_t)f16 * 4;
+    unsigned o[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        int4 c4 = cc[q];
+        int cv[4] = {c4.x, c4.y, c4.z, c4.w};
+        unsigned nanb = 0;
+        if (VD == TRI_VIS_C64) {
+            const float4* vp = reinterpret_cast<const float4*>(vis) + (a16 * 16 + q * 4) / 2;
+            float4 z0 = vp[0], z1 = vp[1];
+            nanb = ((isnan(z0.x) || isnan(z0.y)) ? 1u : 0u) | ((isnan(z0.z) || isnan(z0.w)) ? 0x100u : 0u) |
+                   ((isnan(z1.x) || isnan(z1.y)) ? 0x10000u : 0u) | ((isnan(z1.z) || isnan(z1.w)) ? 0x1000000u : 0u);
+        } else {
+            float4 z = reinterpret_cast<const float4*>(vis)[(a16 * 16 + q * 4) / 4];
+            nanb = (isnan(z.x) ? 1u : 0u) | (isnan(z.y) ? 0x100u : 0u) | (isnan(z.z) ? 0x10000u : 0u) |
+                   (isnan(z.w) ? 0x1000000u : 0u);
+        }
+        unsigned colb = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) colb |= ((double)cv[k] > col_limit ? 1u : 0u) << (8 * k);
+        o[q] = rowall ? 0x01010101u : (dw[q] | colb | nanb);
+    }
+    uint4 ov = make_uint4(o[0], o[1], o[2], o[3]);
+    reinterpret_cast<uint4*>(out)[a16] = ov;
+    if (update_iter) {
+        uint4* ip = reinterpret_cast<uint4*>(iter) + a16;
+        *ip = or4(*ip, ov);
+    }
+}
+
+template <int MODE>
+__global__ void k_masked_div4(const float* __restrict__ w, float* __restrict__ o,
+                              const float* __restrict__ data, size_t n4per, size_t ws_wo, size_t ws_data) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4per) return;
+    size_t win = blockIdx.y;
+    float4 wv = reinterpret_cast<const float4*>(w + win * ws_wo)[i];
+    float4* po = reinterpret_cast<float4*>(o + win * ws_wo) + i;
+    float4 ov = *po;
+    float bg[4] = {(wv.x == 0.0f) ? NAN : ov.x / wv.x, (wv.y == 0.0f) ? NAN : ov.y / wv.y,
+                   (wv.z == 0.0f) ? NAN : ov.z / wv.z, (wv.w == 0.0f) ? NAN : ov.w / wv.w};
+    if (MODE == 1) {
+        float4 dv = reinterpret_cast<const float4*>(data + win * ws_data)[i];
+        bg[0] = fabsf(dv.x - bg[0]); bg[1] = fabsf(dv.y - bg[1]);
+        bg[2] = fabsf(dv.z - bg[2]); bg[3] = fabsf(dv.w - bg[3]);
+    }
+    *po = make_float4(bg[0], bg[1], bg[2], bg[3]);
+}
+
+__global__ void k_sub4(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                       size_t n4per, size_t ws_a, size_t ws_b, size_t ws_o) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4per) return;
+    size_t win = blockIdx.y;
+    float4 x = reinterpret_cast<const float4*>(a + win * ws_a)[i];
+    float4 y = reinterpret_cast<const float4*>(b + win * ws_b)[i];
+    reinterpret_cast<float4*>(out + win * ws_o)[i] = make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w);
+}
+
+// k_reject<true>, 4 samples per thread (C % 4 == 0 keeps a group in one line)
+__global__ void k_reject4(const float* __restrict__ resid, uint8_t* __restrict__ flags,
+                          const double* __restrict__ med, const int* __restrict__ chunk_of,
+                          double scale, int C4, int G, size_t n4per, size_t ws_resid, size_t ws_flags) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4per) return;
+    size_t win = blockIdx.y;
+    int l = (int)(i / C4);
+    double thr = med[win * G + chunk_of[l]] * scale;
+    float4 rv = reinterpret_cast<const float4*>(resid + win * ws_resid)[i];
+    uchar4* pf = reinterpret_cast<uchar4*>(flags + win * ws_flags) + i;
+    uchar4 f = *pf;
+    if ((double)rv.x > thr) f.x = 1;
+    if ((double)rv.y > thr) f.y = 1;
+    if ((double)rv.z > thr) f.z = 1;
+    if ((double)rv.w > thr) f.w = 1;
+    *pf = f;
+}
+
+// ---------------------------------------------------------------------------
 // pack / unpack (packing.py:243-278, 369-415) with a precomputed row map
 // ---------------------------------------------------------------------------
 __global__ void k_fill_windows(float2* __restrict__ vis, uint8_t* __restrict__ flags, size_t n) {
@@ -959,6 +1342,7 @@ struct Plan {
     int64_t r0max, r1max;   // largest box radii along time / frequency
     int64_t PT, PF;         // padded line lengths
     int nit;                // background_iterations
+    bool vec;               // 16-byte vectorised elementwise kernels usable
     StWin swT, swF;
 };
 
@@ -1000,6 +1384,7 @@ int make_plan(int64_t T, int64_t F, const tri_params* p, Plan* pl) {
     }
     if (p->chunk_ends[0] != 0 || p->chunk_ends[pl->G] != pl->Fa) return set_err(TRI_EINVAL, "freq chunk ends must start at 0 and end at the averaged channel count");
     pl->nit = (int)p->background_iterations;
+    pl->vec = (pl->avg == 1 && F % 16 == 0 && T % 4 == 0);
     int64_t emax = std::max<int64_t>(pl->nit, 1);
     pl->r0max = box_radius((double)emax * p->spike_width_time);
     pl->r1max = box_radius((double)emax * p->spike_width_freq);
@@ -1030,7 +1415,7 @@ struct Ws {
     double* med;      // medians: max(Fa, T*G) per window
     // spectrum layout [Fa][Wb]
     float *sdata, *sw, *so, *sres;
-    uint8_t *sflags, *sbgf, *sout;
+    uint8_t *sflags, *sbgf, *sout, *srows;   // srows: sout as rows [Wb][Fa]
     double* smed;     // [Wb][G]
     // SumThreshold scratch
     double* ring;
@@ -1086,6 +1471,7 @@ static void carve(const Plan& pl, int64_t Wb, void* base, size_t cap, bool dry, 
     ws->sflags = b.get<uint8_t>(Fa * W);
     ws->sbgf = b.get<uint8_t>(Fa * W);
     ws->sout = b.get<uint8_t>(Fa * W);
+    ws->srows = b.get<uint8_t>(Fa * W);
     ws->smed = b.get<double>(W * G);
     // SumThreshold scratch: one slot set per (window, chunk, column) thread
     size_t thrT = W * Fa, thrF = W * T * G;
@@ -1243,10 +1629,50 @@ int launch_median(const Run& r, const float* data, const uint8_t* flags, double*
     return TRI_OK;
 }
 
+// LDS budget of the single-sweep filter: 4 stages x 2r slots x BT threads x 4 B.
+// Returns the block size to use, or 0 when the radius is too large and the
+// in-place multi-pass kernel must be used instead.
+int colfilter_lds_block(int rad, int C) {
+    static const bool disabled = [] {
+        const char* e = getenv("TRI_FILTER_MULTIPASS");
+        return e && e[0] == '1';
+    }();
+    if (disabled || rad <= 0) return 0;
+    int bt = rad <= 10 ? 256 : (rad <= 20 ? 128 : (rad <= 40 ? 64 : 0));
+    if (bt == 0) return 0;
+    while (bt > 64 && bt / 2 >= C) bt /= 2;
+    return bt;
+}
+
+// One axis of masked_gaussian_filter's two box filters (weight image and
+// data image) on a column-layout image pair.
+//   srcmode 0: images are built on the fly from (srcData, srcFlags) [n][C]
+//   srcmode 1: images are float arrays; for the multi-pass kernel they sit in
+//              rows [4r, 4r+n) of bufW / bufO, for the LDS kernel in rows [0,n)
+// Output: rows [0,n) of dstW / dstO.
 int launch_colfilter(const Run& r, int srcmode, float* bufW, float* bufO, const float* srcData,
                      const uint8_t* srcFlags, float* dstW, float* dstO, int n, int C, int rad,
                      size_t bws, size_t sws, size_t dws, int64_t W) {
     float denom = box_denominator(rad);
+    int bt = colfilter_lds_block(rad, C);
+    if (bt > 0) {
+        size_t lds = (size_t)4 * 2 * rad * bt * sizeof(float);
+        dim3 grid((unsigned)cdiv(C, bt), (unsigned)W, 2);
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        if (srcmode == 0)
+            hipLaunchKernelGGL(k_colfilter_lds<0>, grid, dim3(bt), lds, r.st, (const float*)nullptr, (const float*)nullptr,
+                               srcData, srcFlags, dstW, dstO, n, C, rad, denom, (size_t)0, sws, dws);
+        else
+            hipLaunchKernelGGL(k_colfilter_lds<1>, grid, dim3(bt), lds, r.st, (const float*)bufW, (const float*)bufO,
+                               srcData, srcFlags, dstW, dstO, n, C, rad, denom, bws, sws, dws);
+        LAUNCHCHK();
+        return TRI_OK;
+    }
     int blk = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
     dim3 grid((unsigned)cdiv(C, blk), (unsigned)W, 2);
     if (srcmode == 0)
@@ -1287,6 +1713,44 @@ int launch_transpose(const Run& r, const T* src, T* dst, int R, int C, size_t sw
     return TRI_OK;
 }
 
+
+// ---- elementwise launch helpers (vector path when the plan allows) ----------
+template <int OP>
+int launch_u8(const Run& r, const uint8_t* a, uint8_t* b, size_t nper, size_t ws_a, size_t ws_b, int64_t W) {
+    if (r.pl.vec && nper % 16 == 0 && ws_a % 16 == 0 && ws_b % 16 == 0) {
+        hipLaunchKernelGGL(k_u8_op16<OP>, grid1(nper / 16, W), dim3(256), 0, r.st, a, b, nper / 16, ws_a, ws_b);
+    } else if (OP == 0) {
+        for (int64_t w = 0; w < W; w++)
+            hipLaunchKernelGGL(k_copy_u8, dim3((unsigned)cdiv(nper, 256)), dim3(256), 0, r.st, a + w * ws_a, b + w * ws_b, nper);
+    } else if (OP == 1) {
+        hipLaunchKernelGGL(k_or, grid1(nper, W), dim3(256), 0, r.st, b, a, nper, ws_b, ws_a);
+    } else {
+        for (int64_t w = 0; w < W; w++)
+            hipLaunchKernelGGL(k_normalise_flags, dim3((unsigned)cdiv(nper, 256)), dim3(256), 0, r.st, a + w * ws_a, b + w * ws_b, nper);
+    }
+    LAUNCHCHK();
+    return TRI_OK;
+}
+
+template <int MODE>
+int launch_masked_div(const Run& r, const float* w, float* o, const float* data, size_t nper, size_t ws_wo, size_t ws_data, int64_t W) {
+    if (nper % 4 == 0 && ws_wo % 4 == 0 && ws_data % 4 == 0 && ((uintptr_t)w % 16 == 0) && ((uintptr_t)o % 16 == 0))
+        hipLaunchKernelGGL(k_masked_div4<MODE>, grid1(nper / 4, W), dim3(256), 0, r.st, w, o, data, nper / 4, ws_wo, ws_data);
+    else
+        hipLaunchKernelGGL(k_masked_div<MODE>, grid1(nper, W), dim3(256), 0, r.st, w, o, data, nper, ws_wo, ws_data);
+    LAUNCHCHK();
+    return TRI_OK;
+}
+
+int launch_sub(const Run& r, const float* a, const float* b, float* out, size_t nper, size_t ws_a, size_t ws_b, size_t ws_o, int64_t W) {
+    if (nper % 4 == 0 && ws_a % 4 == 0 && ws_b % 4 == 0 && ws_o % 4 == 0 && ((uintptr_t)a % 16 == 0) && ((uintptr_t)b % 16 == 0) && ((uintptr_t)out % 16 == 0))
+        hipLaunchKernelGGL(k_sub4, grid1(nper / 4, W), dim3(256), 0, r.st, a, b, out, nper / 4, ws_a, ws_b, ws_o);
+    else
+        hipLaunchKernelGGL(k_sub, grid1(nper, W), dim3(256), 0, r.st, a, b, out, nper, ws_a, ws_b, ws_o);
+    LAUNCHCHK();
+    return TRI_OK;
+}
+
 // _get_background2d (flagging.py:516-579) for the median spectra of the batch,
 // held in spectrum layout [Fa][Wb] (line axis = channel, column = window).
 // Result: rows [0,Fa) of ws.so hold the background.
@@ -1310,11 +1774,9 @@ int spectrum_background(const Run& r) {
             LAUNCHCHK();
         }
         if (final_pass) {
-            hipLaunchKernelGGL(k_masked_div<0>, grid1(nS, 1), dim3(256), 0, r.st, ws.sw, ws.so, ws.sdata, nS, (size_t)0, (size_t)0);
-            LAUNCHCHK();
+            { int rc2 = launch_masked_div<0>(r, ws.sw, ws.so, ws.sdata, nS, 0, 0, 1); if (rc2) return rc2; }
         } else {
-            hipLaunchKernelGGL(k_masked_div<1>, grid1(nS, 1), dim3(256), 0, r.st, ws.sw, ws.so, ws.sdata, nS, (size_t)0, (size_t)0);
-            LAUNCHCHK();
+            { int rc2 = launch_masked_div<1>(r, ws.sw, ws.so, ws.sdata, nS, 0, 0, 1); if (rc2) return rc2; }
             // per (window, chunk) median of the residual: element (f, w) at f*Wn + w
             // -> row = w (RS 1), element stride Wn
             int rc = launch_median(r, ws.so, ws.sbgf, ws.smed, 0, 0, 1, (size_t)Wn, ws.segC_start, ws.segC_len, Wn, G, 1);
@@ -1338,9 +1800,9 @@ int background2d(const Run& r) {
     int64_t W = r.Wb;
     size_t N = (size_t)T * Fa;
     size_t wsA = (size_t)pl.PT * Fa, wsB = (size_t)pl.PF * T;
-    hipLaunchKernelGGL(k_copy_u8, dim3((unsigned)cdiv(N * W, 256)), dim3(256), 0, r.st, ws.flagsTF, ws.bgfTF, N * (size_t)W);
-    LAUNCHCHK();
-    int rc = launch_transpose<uint8_t>(r, ws.bgfTF, ws.bgfFT, T, Fa, N, N, W);
+    int rc = launch_u8<0>(r, ws.flagsTF, ws.bgfTF, N, N, N, W);
+    if (rc) return rc;
+    rc = launch_transpose<uint8_t>(r, ws.bgfTF, ws.bgfFT, T, Fa, N, N, W);
     if (rc) return rc;
     double rej = TRI_MAD_NORMAL * r.p->background_reject;
     for (int ext = pl.nit; ext >= 0; ext--) {
@@ -1356,8 +1818,9 @@ int background2d(const Run& r) {
             hipLaunchKernelGGL(k_build_wo, grid1(N, W), dim3(256), 0, r.st, ws.dataTF, ws.bgfTF, ws.Aw, ws.Ao, N, N, wsA);
             LAUNCHCHK();
         }
-        // --- to FT layout, into rows [4 r1, 4 r1 + Fa) of the padded buffers ---
-        size_t off = (size_t)4 * r1 * T;
+        // --- to FT layout: rows [4 r1, 4 r1 + Fa) of the padded buffers for the
+        //     in-place multi-pass filter, rows [0, Fa) for the single-sweep one ---
+        size_t off = colfilter_lds_block(r1, T) > 0 ? 0 : (size_t)4 * r1 * T;
         rc = launch_transpose<float>(r, ws.Aw, ws.Bw + off, T, Fa, wsA, wsB, W);
         if (rc) return rc;
         rc = launch_transpose<float>(r, ws.Ao, ws.Bo + off, T, Fa, wsA, wsB, W);
@@ -1368,15 +1831,18 @@ int background2d(const Run& r) {
             if (rc) return rc;
         }
         if (final_pass) {
-            hipLaunchKernelGGL(k_masked_div<0>, grid1(N, W), dim3(256), 0, r.st, ws.Bw, ws.Bo, ws.dataFT, N, wsB, N);
-            LAUNCHCHK();
+            rc = launch_masked_div<0>(r, ws.Bw, ws.Bo, ws.dataFT, N, wsB, N, W);
+            if (rc) return rc;
         } else {
-            hipLaunchKernelGGL(k_masked_div<1>, grid1(N, W), dim3(256), 0, r.st, ws.Bw, ws.Bo, ws.dataFT, N, wsB, N);
-            LAUNCHCHK();
+            rc = launch_masked_div<1>(r, ws.Bw, ws.Bo, ws.dataFT, N, wsB, N, W);
+            if (rc) return rc;
             // block medians over (all times) x (chunk channels): contiguous in FT
             rc = launch_median(r, ws.Bo, ws.bgfFT, ws.med, wsB, N, 0, 1, ws.segB_start, ws.segB_len, 1, G, W);
             if (rc) return rc;
-            hipLaunchKernelGGL(k_reject<true>, grid1(N, W), dim3(256), 0, r.st, ws.Bo, ws.bgfFT, ws.med, ws.d_chunk_of, rej, Fa, T, G, wsB, N);
+            if (r.pl.vec && wsB % 4 == 0)
+                hipLaunchKernelGGL(k_reject4, grid1(N / 4, W), dim3(256), 0, r.st, ws.Bo, ws.bgfFT, ws.med, ws.d_chunk_of, rej, T / 4, G, N / 4, wsB, N);
+            else
+                hipLaunchKernelGGL(k_reject<true>, grid1(N, W), dim3(256), 0, r.st, ws.Bo, ws.bgfFT, ws.med, ws.d_chunk_of, rej, Fa, T, G, wsB, N);
             LAUNCHCHK();
             rc = launch_transpose<uint8_t>(r, ws.bgfFT, ws.bgfTF, Fa, T, N, N, W);
             if (rc) return rc;
@@ -1401,7 +1867,10 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
     int rc;
 
     // flagging.py:756  _average_freq
-    hipLaunchKernelGGL(k_prepare<VD>, grid1(N, W), dim3(256), 0, r.st, vis, iter_flags, ws.dataTF, ws.flagsTF, T, F, Fa, (int)pl.avg);
+    if (pl.vec)
+        hipLaunchKernelGGL(k_prepare4<VD>, dim3((unsigned)cdiv(N * (size_t)W / 4, 256)), dim3(256), 0, r.st, vis, iter_flags, ws.dataTF, ws.flagsTF, N * (size_t)W / 4);
+    else
+        hipLaunchKernelGGL(k_prepare<VD>, grid1(N, W), dim3(256), 0, r.st, vis, iter_flags, ws.dataTF, ws.flagsTF, T, F, Fa, (int)pl.avg);
     LAUNCHCHK();
     rc = launch_transpose<float>(r, ws.dataTF, ws.dataFT, T, Fa, N, N, W);
     if (rc) return rc;
@@ -1418,15 +1887,20 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
     rc = spectrum_background(r);
     if (rc) return rc;
     size_t nS = (size_t)Fa * Wn;
-    hipLaunchKernelGGL(k_sub, grid1(nS, 1), dim3(256), 0, r.st, ws.sdata, ws.so, ws.sres, nS, (size_t)0, (size_t)0, (size_t)0);
-    LAUNCHCHK();
+    rc = launch_sub(r, ws.sdata, ws.so, ws.sres, nS, 0, 0, 0, 1);
+    if (rc) return rc;
     rc = launch_median(r, ws.sres, ws.sflags, ws.smed, 0, 0, 1, (size_t)Wn, ws.segC_start, ws.segC_len, Wn, G, 1);
     if (rc) return rc;
     rc = launch_colst(r, pl.swF, ws.sres, ws.smed, ws.sout, ws.d_chunk_ends, Fa, Wn, G, 0, 0, 1);
     if (rc) return rc;
 
     // flagging.py:954  flags |= spec_flags
-    hipLaunchKernelGGL(k_or_spec, grid1(N, W), dim3(256), 0, r.st, ws.flagsTF, ws.sout, T, Fa, Wn);
+    if (pl.vec) {
+        hipLaunchKernelGGL(k_spec_rows, dim3((unsigned)cdiv(nS, 256)), dim3(256), 0, r.st, ws.sout, ws.srows, Fa, Wn);
+        hipLaunchKernelGGL(k_or_spec16, grid1(N / 16, W), dim3(256), 0, r.st, ws.flagsTF, ws.srows, T, Fa / 16);
+    } else {
+        hipLaunchKernelGGL(k_or_spec, grid1(N, W), dim3(256), 0, r.st, ws.flagsTF, ws.sout, T, Fa, Wn);
+    }
     LAUNCHCHK();
 
     // flagging.py:957-962  2-D background (FT layout, ws.Bo), then the residual
@@ -1435,8 +1909,8 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
     if (tap && r.dbg) {
         HIPCHK(hipMemcpyAsync(r.dbg->f32 + Fa, ws.Bo, N * sizeof(float), hipMemcpyDeviceToDevice, r.st));
     }
-    hipLaunchKernelGGL(k_sub, grid1(N, W), dim3(256), 0, r.st, ws.dataFT, ws.Bo, ws.Bo, N, N, wsB, wsB);
-    LAUNCHCHK();
+    rc = launch_sub(r, ws.dataFT, ws.Bo, ws.Bo, N, N, wsB, wsB, W);
+    if (rc) return rc;
     float* residFT = ws.Bo;   // window stride wsB
     float* residTF = ws.Aw;   // window stride N (the time-axis scratch is free again)
     rc = launch_transpose<float>(r, residFT, residTF, Fa, T, wsB, N, W);
@@ -1453,8 +1927,8 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
 
     // flagging.py:967-969  flags |= time_flags; SumThreshold along frequency.
     // MAD per (time, chunk) = contiguous row segments of the TF layout.
-    hipLaunchKernelGGL(k_or, grid1(N, W), dim3(256), 0, r.st, ws.flagsTF, ws.tflTF, N, N, N);
-    LAUNCHCHK();
+    rc = launch_u8<1>(r, ws.tflTF, ws.flagsTF, N, N, N, W);
+    if (rc) return rc;
     rc = launch_median(r, residTF, ws.flagsTF, ws.med, N, N, (size_t)Fa, 1, ws.segC_start, ws.segC_len, T, G, W);
     if (rc) return rc;
     rc = launch_colst(r, pl.swF, residFT, ws.med, ws.fflFT, ws.d_chunk_ends, Fa, T, G, wsB, N, W);
@@ -1476,7 +1950,10 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
         int64_t e = p->time_extend;
         int64_t half = e >= 0 ? e / 2 : -((-e + 1) / 2);   // Python floor division
         int lo = (int)-half, hi = (int)(-half + e);
-        hipLaunchKernelGGL(k_combine, grid1(N, W), dim3(256), 0, r.st, ws.sout, ws.tflTF, ws.fflTF, ws.comb, T, Fa, Wn, lo, hi);
+        if (pl.vec)
+            hipLaunchKernelGGL(k_combine16, grid1(N / 16, W), dim3(256), 0, r.st, ws.srows, ws.tflTF, ws.fflTF, ws.comb, T, Fa / 16, lo, hi);
+        else
+            hipLaunchKernelGGL(k_combine, grid1(N, W), dim3(256), 0, r.st, ws.sout, ws.tflTF, ws.fflTF, ws.comb, T, Fa, Wn, lo, hi);
         LAUNCHCHK();
     }
     // flagging.py:975  _unaverage_freq (replication, frequency smearing, counts)
@@ -1485,15 +1962,24 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
         int64_t half = e >= 0 ? e / 2 : -((-e + 1) / 2);
         int lo = (int)-half, hi = (int)(-half + e);
         HIPCHK(hipMemsetAsync(ws.rowcnt, 0, (size_t)W * T * sizeof(int), r.st));
-        HIPCHK(hipMemsetAsync(ws.colcnt, 0, (size_t)W * F * sizeof(int), r.st));
-        dim3 grid((unsigned)cdiv(F, 256), (unsigned)T, (unsigned)W);
-        hipLaunchKernelGGL(k_unaverage, grid, dim3(256), 0, r.st, ws.comb, ws.dil, ws.rowcnt, ws.colcnt, T, Fa, F, (int)pl.avg, lo, hi);
+        if (pl.vec && lo == -1 && hi == 2) {
+            dim3 grid((unsigned)cdiv(F / 16, 64), (unsigned)T, (unsigned)W);
+            hipLaunchKernelGGL((k_unaverage16<-1, 3>), grid, dim3(64), 0, r.st, ws.comb, ws.dil, ws.rowcnt, T, F / 16);
+            hipLaunchKernelGGL(k_colcount, grid1(F / 4, W), dim3(256), 0, r.st, ws.dil, ws.colcnt, T, F / 4);
+        } else {
+            HIPCHK(hipMemsetAsync(ws.colcnt, 0, (size_t)W * F * sizeof(int), r.st));
+            dim3 grid((unsigned)cdiv(F, 256), (unsigned)T, (unsigned)W);
+            hipLaunchKernelGGL(k_unaverage, grid, dim3(256), 0, r.st, ws.comb, ws.dil, ws.rowcnt, ws.colcnt, T, Fa, F, (int)pl.avg, lo, hi);
+        }
         LAUNCHCHK();
     }
     // flagging.py:910-918 whole-row / whole-column rules; :777-781 NaN OR; :1193
     double row_limit = p->flag_all_freq_frac * (double)F;
     double col_limit = (double)T * p->flag_all_time_frac;
-    hipLaunchKernelGGL(k_final<VD>, grid1(NF, W), dim3(256), 0, r.st, ws.dil, ws.rowcnt, ws.colcnt, vis, out_flags, iter_flags, T, F, row_limit, col_limit, update_iter ? 1 : 0);
+    if (pl.vec)
+        hipLaunchKernelGGL(k_final16<VD>, grid1(NF / 16, W), dim3(256), 0, r.st, ws.dil, ws.rowcnt, ws.colcnt, vis, out_flags, iter_flags, T, F / 16, row_limit, col_limit, update_iter ? 1 : 0);
+    else
+        hipLaunchKernelGGL(k_final<VD>, grid1(NF, W), dim3(256), 0, r.st, ws.dil, ws.rowcnt, ws.colcnt, vis, out_flags, iter_flags, T, F, row_limit, col_limit, update_iter ? 1 : 0);
     LAUNCHCHK();
     return TRI_OK;
 }
@@ -1511,6 +1997,8 @@ int flagger_impl(const void* vis, int vis_dtype, const uint8_t* flags, uint8_t* 
     int rc = make_plan(T, F, p, &r.pl);
     if (rc) return rc;
     if (r.pl.G > TRI_MAX_CHUNKS) return set_err(TRI_EUNSUPPORTED, "at most %d frequency chunks", TRI_MAX_CHUNKS);
+    // the 16-byte kernels need 16-byte aligned user buffers (torch allocations are)
+    if ((((uintptr_t)vis) | ((uintptr_t)flags) | ((uintptr_t)out_flags)) & 15) r.pl.vec = false;
     if (n_cp == 0) return TRI_OK;
     if (!workspace) return set_err(TRI_EWORKSPACE, "NULL workspace");
     if (((uintptr_t)workspace & 255) != 0) return set_err(TRI_EINVAL, "workspace must be 256-byte aligned");
@@ -1549,8 +2037,8 @@ int flagger_impl(const void* vis, int vis_dtype, const uint8_t* flags, uint8_t* 
         uint8_t* out_b = out_flags + (size_t)w0 * NF;
         size_t nb = (size_t)r.Wb * NF;
         // flagging.py:1182  iter_flags = flags.copy()  (non-zero = flagged)
-        hipLaunchKernelGGL(k_normalise_flags, dim3((unsigned)cdiv(nb, 256)), dim3(256), 0, r.st, flags + (size_t)w0 * NF, r.ws.iter, nb);
-        LAUNCHCHK();
+        rc = launch_u8<2>(r, flags + (size_t)w0 * NF, r.ws.iter, NF, NF, NF, r.Wb);
+        if (rc) return rc;
         for (int64_t it = 0; it < p->num_major_iterations; it++) {
             bool last = it == p->num_major_iterations - 1;
             bool tap = last && w0 == 0;
