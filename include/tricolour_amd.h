@@ -194,6 +194,19 @@ int tri_sum_threshold_flagger_debug(const void *vis, int vis_dtype,
                                     void *workspace, size_t workspace_bytes,
                                     void *stream, float *dbg_f32, uint8_t *dbg_u8);
 
+/*
+ * Test hook: exact segmented medians of |x| over the unflagged samples of a
+ * (n_win, rows, row_len) float32 array; segments [seg_ends[g], seg_ends[g+1])
+ * (HOST array) along each row; med is (n_win, rows, n_seg_ends - 1) float64,
+ * NaN where a segment has no unflagged sample.  variant 0 = automatic,
+ * 1 = wave kernel, 2 / 3 = workgroup kernel with scalar / vector loads.
+ * Restates _median_abs / _median_abs_axis0 (flagging.py:267-304).
+ */
+int tri_test_median(const float *data, const uint8_t *flags, double *med,
+                    int64_t n_win, int64_t rows, int64_t row_len,
+                    const int64_t *seg_ends, int64_t n_seg_ends, int variant,
+                    void *stream);
+
 /* Device amplitude of complex64 samples, the |z| used at flagging.py:856
  * (libm hypotf semantics); exposed so the tests can pin it (golden G0). */
 int tri_abs_c64(const void *z_c64, float *out, int64_t n, void *stream);

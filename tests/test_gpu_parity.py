@@ -154,3 +154,55 @@ def test_fused_sumthreshold_kernel_vs_generic_and_oracle(gpu, oracle, shape):
     if windows == [1, 2, 4, 8]:
         fused = _run_st_kernel(data, mad, windows, 4.5, 1.3, 2)
         assert np.array_equal(fused, gen)
+
+
+def _np_median_abs(vals):
+    """numba's np.median on float32: odd -> middle; even -> f32(a + b) / 2 in f64."""
+    v = np.sort(np.abs(vals).astype(np.float32))
+    n = v.size
+    if n == 0:
+        return np.nan
+    if n & 1:
+        return float(v[n // 2])
+    return float(np.float32(v[n // 2 - 1] + v[n // 2])) / 2.0
+
+
+@pytest.mark.parametrize("rows,row_len,ends,variants", [
+    (5, 1024, [0, 1024], (1, 2, 3)),
+    (3, 410, [0, 41, 82, 123, 410], (1, 2)),
+    (2, 4096, [0, 4, 8, 2048, 4096], (2, 3)),
+    (1, 6000, [0, 1, 2, 3001, 6000], (2,)),
+    (4, 64, [0, 0, 1, 2, 64], (1, 2)),
+    (1, 300000, [0, 100000, 300000], (2, 3)),
+])
+def test_median_kernels(gpu, rows, row_len, ends, variants):
+    import ctypes as C
+    import torch
+    from tricolour_amd import _lib
+    rs = np.random.RandomState(rows * 1000 + row_len)
+    n_win = 2
+    data = rs.standard_normal((n_win, rows, row_len)).astype(np.float32)
+    data[0, 0, : row_len // 2] = np.float32(0.5)          # heavy duplicates
+    data[1, -1] *= np.float32(1e-20)                       # tiny magnitudes
+    data[0, -1, ::3] *= np.float32(1e12)                   # wide dynamic range
+    flags = rs.uniform(size=data.shape) < 0.3
+    flags[1, 0, :] = True                                   # nothing unflagged
+    if rows > 1:
+        flags[0, 1, :] = False
+    G = len(ends) - 1
+    exp = np.empty((n_win, rows, G))
+    for w in range(n_win):
+        for r in range(rows):
+            for g in range(G):
+                seg = slice(ends[g], ends[g + 1])
+                exp[w, r, g] = _np_median_abs(data[w, r, seg][~flags[w, r, seg]])
+    d = torch.from_numpy(data).cuda()
+    f = torch.from_numpy(flags).cuda().view(torch.uint8)
+    e = (C.c_int64 * len(ends))(*ends)
+    for variant in variants:
+        med = torch.full((n_win, rows, G), -1.0, dtype=torch.float64, device="cuda")
+        _lib.check(_lib.lib().tri_test_median(d.data_ptr(), f.data_ptr(), med.data_ptr(), n_win, rows,
+                                              row_len, e, len(ends), variant, None))
+        got = med.cpu().numpy()
+        same = (got == exp) | (np.isnan(got) & np.isnan(exp))
+        assert same.all(), "variant %d: %d medians differ" % (variant, (~same).sum())

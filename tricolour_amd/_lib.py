@@ -104,6 +104,8 @@ _SIGNATURES = {
                                          C.c_int64, C.c_int64, C.POINTER(C.c_int64),
                                          C.c_int64, C.c_double, C.c_double, C.c_int,
                                          C.c_int, C.POINTER(C.c_float), C.c_void_p]),
+    "tri_test_median": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                  C.c_int64, C.POINTER(C.c_int64), C.c_int64, C.c_int, C.c_void_p]),
     "tri_abs_c64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
 }
 

@@ -156,6 +156,34 @@ __global__ void k_transpose(const T* __restrict__ src, T* __restrict__ dst, int 
     }
 }
 
+// uint8 transpose with 4-byte accesses on both sides (R % 4 == 0, C % 4 == 0):
+// 64x64 byte tile; thread (tx, ty) of a (16,16) block moves uchar4 groups.
+__global__ void k_transpose_u8x4(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int R,
+                                 int C, size_t src_ws, size_t dst_ws) {
+    __shared__ uint8_t tile[64][68];
+    const uint8_t* s = src + (size_t)blockIdx.z * src_ws;
+    uint8_t* d = dst + (size_t)blockIdx.z * dst_ws;
+    int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    int tx = threadIdx.x, ty = threadIdx.y;   // 16 x 16
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int r = r0 + ty + 16 * j, c = c0 + 4 * tx;
+        uchar4 v = make_uchar4(0, 0, 0, 0);
+        if (r < R && c < C) v = *reinterpret_cast<const uchar4*>(s + (size_t)r * C + c);
+        *reinterpret_cast<uchar4*>(&tile[ty + 16 * j][4 * tx]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int c = c0 + ty + 16 * j, r = r0 + 4 * tx;   // output row = source column
+        if (c < C && r < R) {
+            int cc = ty + 16 * j;
+            uchar4 v = make_uchar4(tile[4 * tx][cc], tile[4 * tx + 1][cc], tile[4 * tx + 2][cc], tile[4 * tx + 3][cc]);
+            *reinterpret_cast<uchar4*>(d + (size_t)c * R + r) = v;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // K3  segmented exact median of |x| over unflagged samples ("row select").
 // np.median under numba (np/arraymath.py:1365-1399): odd n -> middle element,
@@ -170,13 +198,23 @@ __global__ void k_transpose(const T* __restrict__ src, T* __restrict__ dst, int 
 // grid (R*G, W), block 256
 // ---------------------------------------------------------------------------
 #define SEL_CACHE 8
+#define SEL_BINS 2048
+// Three radix passes over the 31-bit key: digits of 11, 10 and 10 bits.  The
+// even-count partner (rank n/2 - 1) needs no extra pass: it equals the median
+// key when that key is duplicated below rank n/2, else the largest occupied
+// bin below it in the last histogram, else the largest key with a smaller
+// 21-bit prefix (tracked during the last pass).
+// VEC: segments are contiguous, 16-byte aligned and a multiple of 4 long ->
+// float4 / uchar4 loads.
+template <bool VEC>
 __global__ void __launch_bounds__(256)
 k_median(const float* __restrict__ data, const uint8_t* __restrict__ flags,
          double* __restrict__ med, size_t WSd, size_t WSf, size_t RS, size_t ES,
          const int64_t* __restrict__ seg_start, const int64_t* __restrict__ seg_len,
          int R, int G) {
-    __shared__ unsigned hist[256];
-    __shared__ unsigned sh_prefix, sh_k, sh_n, sh_cnt, sh_max;
+    __shared__ unsigned hist[SEL_BINS];
+    __shared__ unsigned sh_wsum[4];
+    __shared__ unsigned sh_prefix, sh_k, sh_sel, sh_maxbelow, sh_lobin1;
     const unsigned SENT = 0xFFFFFFFFu;
     int seg = blockIdx.x;
     int row = seg / G, g = seg % G;
@@ -185,9 +223,8 @@ k_median(const float* __restrict__ data, const uint8_t* __restrict__ flags,
     size_t rel = (size_t)row * RS + (size_t)seg_start[g] * ES;
     data += win * WSd + rel;
     flags += win * WSf + rel;
-    const size_t base = 0;
-    int tid = threadIdx.x;
-    bool cached = len <= (int64_t)SEL_CACHE * 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool cached = !VEC && len <= (int64_t)SEL_CACHE * 256;
     unsigned keys[SEL_CACHE];
     if (cached) {
 #pragma unroll
@@ -195,105 +232,247 @@ k_median(const float* __restrict__ data, const uint8_t* __restrict__ flags,
             int64_t i = (int64_t)u * 256 + tid;
             unsigned k = SENT;
             if (i < len) {
-                size_t a = base + (size_t)i * ES;
+                size_t a = (size_t)i * ES;
                 if (!flags[a]) k = __float_as_uint(data[a]) & 0x7FFFFFFFu;
             }
             keys[u] = k;
         }
     }
+    if (tid == 0) { sh_maxbelow = 0; sh_lobin1 = 0; }
     unsigned prefix = 0, pmask = 0, kk = 0, n = 0;
-    for (int p = 0; p < 4; p++) {
-        int shift = 24 - 8 * p;
-        hist[tid] = 0;
+    for (int p = 0; p < 3; p++) {
+        const int shift = p == 0 ? 20 : (p == 1 ? 10 : 0);
+        const unsigned dm = p == 0 ? 0x7FFu : 0x3FFu;
+#pragma unroll
+        for (int u = 0; u < SEL_BINS / 256; u++) hist[u * 256 + tid] = 0;
         __syncthreads();
+        unsigned mb = 0;
+        auto visit = [&](unsigned k) {
+            if ((k & pmask) == prefix) atomicAdd(&hist[(k >> shift) & dm], 1u);
+            else if (p == 2 && k < prefix) mb = max(mb, k);
+        };
         if (cached) {
 #pragma unroll
-            for (int u = 0; u < SEL_CACHE; u++) {
-                unsigned k = keys[u];
-                if (k != SENT && (k & pmask) == prefix) atomicAdd(&hist[(k >> shift) & 0xFFu], 1u);
+            for (int u = 0; u < SEL_CACHE; u++)
+                if (keys[u] != SENT) visit(keys[u]);
+        } else if (VEC) {
+            const float4* d4 = reinterpret_cast<const float4*>(data);
+            const uchar4* f4 = reinterpret_cast<const uchar4*>(flags);
+            for (int64_t i = tid; i < len / 4; i += 256) {
+                float4 dv = d4[i];
+                uchar4 fv = f4[i];
+                if (!fv.x) visit(__float_as_uint(dv.x) & 0x7FFFFFFFu);
+                if (!fv.y) visit(__float_as_uint(dv.y) & 0x7FFFFFFFu);
+                if (!fv.z) visit(__float_as_uint(dv.z) & 0x7FFFFFFFu);
+                if (!fv.w) visit(__float_as_uint(dv.w) & 0x7FFFFFFFu);
             }
         } else {
             for (int64_t i = tid; i < len; i += 256) {
-                size_t a = base + (size_t)i * ES;
-                if (!flags[a]) {
-                    unsigned k = __float_as_uint(data[a]) & 0x7FFFFFFFu;
-                    if ((k & pmask) == prefix) atomicAdd(&hist[(k >> shift) & 0xFFu], 1u);
-                }
+                size_t a = (size_t)i * ES;
+                if (!flags[a]) visit(__float_as_uint(data[a]) & 0x7FFFFFFFu);
             }
         }
+        if (p == 2 && mb) atomicMax(&sh_maxbelow, mb);
         __syncthreads();
-        if (tid < 64) {
-            // lane l owns bins 4l..4l+3; wave-wide inclusive scan of lane sums
-            unsigned h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2],
-                     h3 = hist[4 * tid + 3];
-            unsigned s = h0 + h1 + h2 + h3;
-            unsigned inc = s;
-            for (int o = 1; o < 64; o <<= 1) {
-                unsigned v = __shfl_up(inc, o, 64);
-                if (tid >= o) inc += v;
-            }
-            unsigned total = __shfl(inc, 63, 64);
-            unsigned nn = (p == 0) ? total : 0;
-            unsigned ktarget = (p == 0) ? (total >> 1) : sh_k;
-            if (p == 0 && tid == 0) sh_n = total;
-            unsigned exc = inc - s;
-            if (total > 0 && ktarget >= exc && ktarget < inc) {
-                unsigned c = exc;
-                unsigned d;
-                if (ktarget < c + h0) d = 0;
-                else if (ktarget < c + h0 + h1) { d = 1; c += h0; }
-                else if (ktarget < c + h0 + h1 + h2) { d = 2; c += h0 + h1; }
-                else { d = 3; c += h0 + h1 + h2; }
-                sh_prefix = prefix | ((4u * tid + d) << shift);
-                sh_k = ktarget - c;
-            }
-            (void)nn;
+        // bucket search: thread t owns bins [8t, 8t+8)
+        unsigned v[8];
+        {
+            uint4 q0 = reinterpret_cast<const uint4*>(hist)[2 * tid];
+            uint4 q1 = reinterpret_cast<const uint4*>(hist)[2 * tid + 1];
+            v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w;
+            v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+        }
+        unsigned sacc = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) sacc += v[j];
+        unsigned inc = sacc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            unsigned t2 = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t2;
+        }
+        if (lane == 63) sh_wsum[wave] = inc;
+        __syncthreads();
+        unsigned woff = 0, total = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; w2++) {
+            unsigned t2 = sh_wsum[w2];
+            if (w2 < wave) woff += t2;
+            total += t2;
+        }
+        if (p == 0) { n = total; kk = total >> 1; }
+        unsigned exc = woff + inc - sacc;
+        if (total > 0 && kk >= exc && kk < exc + sacc) {
+            unsigned c = exc;
+            int j = 0;
+#pragma unroll
+            for (int q = 0; q < 7; q++)
+                if (j == q && kk >= c + v[q]) { c += v[q]; j = q + 1; }
+            sh_sel = 8u * tid + j;
+            sh_prefix = prefix | ((8u * tid + j) << shift);
+            sh_k = kk - c;
         }
         __syncthreads();
-        if (p == 0) n = sh_n;
         if (n == 0) break;
+        if (p == 2) {
+            unsigned sel = sh_sel, cand = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (v[j] && 8u * tid + j < sel) cand = 8u * tid + j + 1;
+            if (cand) atomicMax(&sh_lobin1, cand);
+        }
         prefix = sh_prefix;
         kk = sh_k;
-        pmask |= 0xFFu << shift;
+        pmask |= dm << shift;
         __syncthreads();
     }
-    (void)kk;
-    size_t oidx = (win * (size_t)R + row) * G + g;
-    if (n == 0) {
-        if (tid == 0) med[oidx] = __longlong_as_double(0x7FF8000000000000LL);
-        return;
-    }
-    unsigned hi = prefix;
-    if (n & 1u) {
-        if (tid == 0) med[oidx] = (double)__uint_as_float(hi);
-        return;
-    }
-    // even count: lo = element of rank n/2 - 1 = max{x < hi} if exactly n/2
-    // elements are below hi, else hi itself (duplicates).
-    if (tid == 0) { sh_cnt = 0; sh_max = 0; }
-    __syncthreads();
-    unsigned cnt = 0, mx = 0;
-    if (cached) {
-#pragma unroll
-        for (int u = 0; u < SEL_CACHE; u++) {
-            unsigned k = keys[u];
-            if (k != SENT && k < hi) { cnt++; mx = max(mx, k); }
+    if (tid == 0) {
+        size_t oidx = (win * (size_t)R + row) * G + g;
+        double m;
+        if (n == 0) m = __longlong_as_double(0x7FF8000000000000LL);
+        else if (n & 1u) m = (double)__uint_as_float(prefix);
+        else {
+            unsigned hi = prefix, lo;
+            if (kk > 0) lo = hi;
+            else if (sh_lobin1) lo = (hi & ~0x3FFu) | (sh_lobin1 - 1);
+            else lo = sh_maxbelow;
+            float sm = __uint_as_float(lo) + __uint_as_float(hi);
+            m = (double)sm / 2.0;
         }
-    } else {
-        for (int64_t i = tid; i < len; i += 256) {
-            size_t a = base + (size_t)i * ES;
-            if (!flags[a]) {
-                unsigned k = __float_as_uint(data[a]) & 0x7FFFFFFFu;
-                if (k < hi) { cnt++; mx = max(mx, k); }
+        med[oidx] = m;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K3b  Wave-per-segment form of k_median for segments of at most 1024 samples
+// (time lines of a window, per-chunk channel runs): the segment's keys stay in
+// registers (16 per lane), each wave owns a 256-bin LDS histogram, and the
+// bucket search is a wave scan -- no workgroup-wide work per segment.  Four
+// segments per 256-thread workgroup; barriers are executed uniformly.
+// grid (ceil(R*G/4), W), block 256
+// ---------------------------------------------------------------------------
+#define MW_K 16
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor(v, o, 64));
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+k_median_wave(const float* __restrict__ data, const uint8_t* __restrict__ flags,
+              double* __restrict__ med, size_t WSd, size_t WSf, size_t RS, size_t ES,
+              const int64_t* __restrict__ seg_start, const int64_t* __restrict__ seg_len,
+              int R, int G) {
+    __shared__ unsigned hist[4][256];
+    const unsigned SENT = 0xFFFFFFFFu;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int seg = blockIdx.x * 4 + wave;
+    const bool live = seg < R * G;
+    const int row = live ? seg / G : 0, g = live ? seg % G : 0;
+    const size_t win = blockIdx.y;
+    const int len = live ? (int)seg_len[g] : 0;
+    const size_t rel = (size_t)row * RS + (size_t)seg_start[g] * ES;
+    const float* d = data + win * WSd + rel;
+    const uint8_t* f = flags + win * WSf + rel;
+    unsigned keys[MW_K];
+    unsigned nloc = 0;
+#pragma unroll
+    for (int u = 0; u < MW_K; u++) {
+        int i = u * 64 + lane;
+        unsigned k = SENT;
+        if (i < len) {
+            size_t a = (size_t)i * ES;
+            if (!f[a]) { k = __float_as_uint(d[a]) & 0x7FFFFFFFu; nloc++; }
+        }
+        keys[u] = k;
+    }
+    const unsigned n = wave_sum_u32(nloc);
+    // Normalise the keys to their minimum and radix-select only the B
+    // significant bits of the spread: the leading digit then follows the
+    // sample distribution (a plain top byte of a float is its exponent, which
+    // puts almost every sample of a line into one or two bins and serialises
+    // the LDS atomics).
+    unsigned kmin = SENT, kmax = 0;
+#pragma unroll
+    for (int u = 0; u < MW_K; u++)
+        if (keys[u] != SENT) { kmin = min(kmin, keys[u]); kmax = max(kmax, keys[u]); }
+    kmin = ~wave_max_u32(~kmin);
+    kmax = wave_max_u32(kmax);
+    const int B = (n == 0 || kmax == kmin) ? 0 : 32 - __clz((int)(kmax - kmin));
+    const int P = (B + 7) >> 3;
+#pragma unroll
+    for (int u = 0; u < MW_K; u++)
+        if (keys[u] != SENT) keys[u] -= kmin;
+    unsigned prefix = 0, pmask = 0, kk = n >> 1;
+    unsigned* h = hist[wave];
+    for (int p = 0; p < 4; p++) {
+        const int shift = max(B - 8 * (p + 1), 0);
+        const bool act = p < P;
+        reinterpret_cast<uint4*>(h)[lane] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+        if (act) {
+#pragma unroll
+            for (int u = 0; u < MW_K; u++) {
+                unsigned k = keys[u];
+                if (k != SENT && (k & pmask) == prefix) atomicAdd(&h[(k >> shift) & 0xFFu], 1u);
             }
         }
+        __syncthreads();
+        if (act) {
+            uint4 hv = reinterpret_cast<uint4*>(h)[lane];
+            unsigned sacc = hv.x + hv.y + hv.z + hv.w;
+            unsigned inc = sacc;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                unsigned v = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += v;
+            }
+            unsigned exc = inc - sacc;
+            bool mine = n > 0 && kk >= exc && kk < inc;
+            unsigned dsel = 0, cbase = exc;
+            if (mine) {
+                if (kk < exc + hv.x) dsel = 0;
+                else if (kk < exc + hv.x + hv.y) { dsel = 1; cbase = exc + hv.x; }
+                else if (kk < exc + hv.x + hv.y + hv.z) { dsel = 2; cbase = exc + hv.x + hv.y; }
+                else { dsel = 3; cbase = exc + hv.x + hv.y + hv.z; }
+            }
+            unsigned long long bm = __ballot(mine);
+            if (bm) {
+                int src = __ffsll((long long)bm) - 1;
+                unsigned digit = __shfl(4u * lane + dsel, src, 64);
+                unsigned base = __shfl(cbase, src, 64);
+                prefix |= digit << shift;   // overlapping bits of a short last digit are already equal
+                kk -= base;
+            }
+            pmask |= 0xFFu << shift;
+        }
+        __syncthreads();
     }
-    if (cnt) { atomicAdd(&sh_cnt, cnt); atomicMax(&sh_max, mx); }
-    __syncthreads();
-    if (tid == 0) {
-        unsigned lo = (sh_cnt == (n >> 1)) ? sh_max : hi;
-        float s = __uint_as_float(lo) + __uint_as_float(hi);  // f32 + f32 -> f32
-        med[oidx] = (double)s / 2.0;                          // f32 / int64 -> f64
+    unsigned cnt = 0, mx = 0;
+#pragma unroll
+    for (int u = 0; u < MW_K; u++) {
+        unsigned k = keys[u];
+        if (k != SENT && k < prefix) { cnt++; mx = max(mx, k); }
+    }
+    cnt = wave_sum_u32(cnt);
+    mx = wave_max_u32(mx) + kmin;
+    const unsigned hi = prefix + kmin;
+    if (live && lane == 0) {
+        size_t oidx = (win * (size_t)R + row) * G + g;
+        double m;
+        if (n == 0) m = __longlong_as_double(0x7FF8000000000000LL);
+        else if (n & 1u) m = (double)__uint_as_float(hi);
+        else {
+            unsigned lo = (cnt == (n >> 1)) ? mx : hi;
+            float sm = __uint_as_float(lo) + __uint_as_float(hi);
+            m = (double)sm / 2.0;
+        }
+        med[oidx] = m;
     }
 }
 
@@ -564,6 +743,20 @@ __global__ void k_build_wo(const float* __restrict__ data, const uint8_t* __rest
     bool fl = flags[win * sws + i] != 0;
     w[win * dws + i] = fl ? 0.0f : 1.0f;
     o[win * dws + i] = fl ? 0.0f : data[win * sws + i];
+}
+
+__global__ void k_build_wo4(const float* __restrict__ data, const uint8_t* __restrict__ flags,
+                            float* __restrict__ w, float* __restrict__ o, size_t n4per,
+                            size_t sws, size_t dws) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4per) return;
+    size_t win = blockIdx.y;
+    uchar4 f = reinterpret_cast<const uchar4*>(flags + win * sws)[i];
+    float4 d = reinterpret_cast<const float4*>(data + win * sws)[i];
+    reinterpret_cast<float4*>(w + win * dws)[i] =
+        make_float4(f.x ? 0.0f : 1.0f, f.y ? 0.0f : 1.0f, f.z ? 0.0f : 1.0f, f.w ? 0.0f : 1.0f);
+    reinterpret_cast<float4*>(o + win * dws)[i] =
+        make_float4(f.x ? 0.0f : d.x, f.y ? 0.0f : d.y, f.z ? 0.0f : d.z, f.w ? 0.0f : d.w);
 }
 
 // ---------------------------------------------------------------------------
@@ -1343,6 +1536,7 @@ struct Plan {
     int64_t PT, PF;         // padded line lengths
     int nit;                // background_iterations
     bool vec;               // 16-byte vectorised elementwise kernels usable
+    int64_t maxchunk;       // longest frequency chunk (averaged channels)
     StWin swT, swF;
 };
 
@@ -1384,6 +1578,8 @@ int make_plan(int64_t T, int64_t F, const tri_params* p, Plan* pl) {
     }
     if (p->chunk_ends[0] != 0 || p->chunk_ends[pl->G] != pl->Fa) return set_err(TRI_EINVAL, "freq chunk ends must start at 0 and end at the averaged channel count");
     pl->nit = (int)p->background_iterations;
+    pl->maxchunk = 0;
+    for (int64_t g = 0; g + 1 < p->n_chunk_ends; g++) pl->maxchunk = std::max(pl->maxchunk, p->chunk_ends[g + 1] - p->chunk_ends[g]);
     pl->vec = (pl->avg == 1 && F % 16 == 0 && T % 4 == 0);
     int64_t emax = std::max<int64_t>(pl->nit, 1);
     pl->r0max = box_radius((double)emax * p->spike_width_time);
@@ -1620,11 +1816,18 @@ bool st_use_fused(const StWin& sw) {
 
 int launch_median(const Run& r, const float* data, const uint8_t* flags, double* med, size_t WSd,
                   size_t WSf, size_t RS, size_t ES, const int64_t* seg_start,
-                  const int64_t* seg_len, int R, int G, int64_t W) {
+                  const int64_t* seg_len, int R, int G, int64_t W, int64_t max_len, bool vec_ok = false) {
     if ((int64_t)R * G <= 0 || W <= 0) return TRI_OK;
     if ((int64_t)R * G > 0x7FFFFFFF || W > 65535) return set_err(TRI_EUNSUPPORTED, "median grid too large");
-    hipLaunchKernelGGL(k_median, dim3((unsigned)(R * G), (unsigned)W), dim3(256), 0, r.st, data,
-                       flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
+    if (max_len <= 64 * MW_K)
+        hipLaunchKernelGGL(k_median_wave, dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)W), dim3(256), 0, r.st,
+                           data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
+    else if (vec_ok)
+        hipLaunchKernelGGL(k_median<true>, dim3((unsigned)(R * G), (unsigned)W), dim3(256), 0, r.st, data,
+                           flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
+    else
+        hipLaunchKernelGGL(k_median<false>, dim3((unsigned)(R * G), (unsigned)W), dim3(256), 0, r.st, data,
+                           flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
     LAUNCHCHK();
     return TRI_OK;
 }
@@ -1708,6 +1911,12 @@ template <typename T>
 int launch_transpose(const Run& r, const T* src, T* dst, int R, int C, size_t sws, size_t dws,
                      int64_t W) {
     dim3 grid((unsigned)cdiv(C, 64), (unsigned)cdiv(R, 64), (unsigned)W);
+    if (sizeof(T) == 1 && R % 4 == 0 && C % 4 == 0 && sws % 4 == 0 && dws % 4 == 0 &&
+        ((uintptr_t)src % 4 == 0) && ((uintptr_t)dst % 4 == 0)) {
+        hipLaunchKernelGGL(k_transpose_u8x4, grid, dim3(16, 16), 0, r.st, (const uint8_t*)src, (uint8_t*)dst, R, C, sws, dws);
+        LAUNCHCHK();
+        return TRI_OK;
+    }
     hipLaunchKernelGGL(k_transpose<T>, grid, dim3(64, 4), 0, r.st, src, dst, R, C, sws, dws);
     LAUNCHCHK();
     return TRI_OK;
@@ -1779,7 +1988,7 @@ int spectrum_background(const Run& r) {
             { int rc2 = launch_masked_div<1>(r, ws.sw, ws.so, ws.sdata, nS, 0, 0, 1); if (rc2) return rc2; }
             // per (window, chunk) median of the residual: element (f, w) at f*Wn + w
             // -> row = w (RS 1), element stride Wn
-            int rc = launch_median(r, ws.so, ws.sbgf, ws.smed, 0, 0, 1, (size_t)Wn, ws.segC_start, ws.segC_len, Wn, G, 1);
+            int rc = launch_median(r, ws.so, ws.sbgf, ws.smed, 0, 0, 1, (size_t)Wn, ws.segC_start, ws.segC_len, Wn, G, 1, pl.maxchunk);
             if (rc) return rc;
             hipLaunchKernelGGL(k_reject<false>, grid1(nS, 1), dim3(256), 0, r.st, ws.so, ws.sbgf, ws.smed, ws.d_chunk_of, rej, Fa, Wn, G, (size_t)0, (size_t)0);
             LAUNCHCHK();
@@ -1811,7 +2020,19 @@ int background2d(const Run& r) {
         int r0 = (int)box_radius(e * r.p->spike_width_time);
         int r1 = (int)box_radius(e * r.p->spike_width_freq);
         // --- time axis (TF layout: line = time, column = channel) ---
-        if (r0 > 0) {
+        // Building the weight / data images first (13 B/sample, vectorised) and
+        // streaming float images through the sequential kernel is faster than
+        // byte loads of the flags inside its per-line loop.
+        static const bool prebuild = [] { const char* e = getenv("TRI_TIME_PREBUILD"); return !(e && e[0] == '0'); }();
+        if (r0 > 0 && prebuild && colfilter_lds_block(r0, Fa) > 0) {
+            if (N % 4 == 0 && wsA % 4 == 0)
+                hipLaunchKernelGGL(k_build_wo4, grid1(N / 4, W), dim3(256), 0, r.st, ws.dataTF, ws.bgfTF, ws.Aw, ws.Ao, N / 4, N, wsA);
+            else
+                hipLaunchKernelGGL(k_build_wo, grid1(N, W), dim3(256), 0, r.st, ws.dataTF, ws.bgfTF, ws.Aw, ws.Ao, N, N, wsA);
+            LAUNCHCHK();
+            rc = launch_colfilter(r, 1, ws.Aw, ws.Ao, nullptr, nullptr, ws.Aw, ws.Ao, T, Fa, r0, wsA, 0, wsA, W);
+            if (rc) return rc;
+        } else if (r0 > 0) {
             rc = launch_colfilter(r, 0, ws.Aw, ws.Ao, ws.dataTF, ws.bgfTF, ws.Aw, ws.Ao, T, Fa, r0, wsA, N, wsA, W);
             if (rc) return rc;
         } else {
@@ -1837,7 +2058,8 @@ int background2d(const Run& r) {
             rc = launch_masked_div<1>(r, ws.Bw, ws.Bo, ws.dataFT, N, wsB, N, W);
             if (rc) return rc;
             // block medians over (all times) x (chunk channels): contiguous in FT
-            rc = launch_median(r, ws.Bo, ws.bgfFT, ws.med, wsB, N, 0, 1, ws.segB_start, ws.segB_len, 1, G, W);
+            rc = launch_median(r, ws.Bo, ws.bgfFT, ws.med, wsB, N, 0, 1, ws.segB_start, ws.segB_len, 1, G, W, pl.maxchunk * pl.T,
+                               T % 4 == 0 && wsB % 4 == 0 && N % 4 == 0);
             if (rc) return rc;
             if (r.pl.vec && wsB % 4 == 0)
                 hipLaunchKernelGGL(k_reject4, grid1(N / 4, W), dim3(256), 0, r.st, ws.Bo, ws.bgfFT, ws.med, ws.d_chunk_of, rej, T / 4, G, N / 4, wsB, N);
@@ -1878,7 +2100,7 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
     if (rc) return rc;
 
     // flagging.py:944  _time_median: rows of the FT layout are contiguous in time
-    rc = launch_median(r, ws.dataFT, ws.flagsFT, ws.med, N, N, (size_t)T, 1, ws.segT_start, ws.segT_len, Fa, 1, W);
+    rc = launch_median(r, ws.dataFT, ws.flagsFT, ws.med, N, N, (size_t)T, 1, ws.segT_start, ws.segT_len, Fa, 1, W, pl.T);
     if (rc) return rc;
     hipLaunchKernelGGL(k_spec_from_med, dim3((unsigned)cdiv((size_t)Fa * Wn, 256)), dim3(256), 0, r.st, ws.med, ws.sdata, ws.sflags, Fa, Wn);
     LAUNCHCHK();
@@ -1889,7 +2111,7 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
     size_t nS = (size_t)Fa * Wn;
     rc = launch_sub(r, ws.sdata, ws.so, ws.sres, nS, 0, 0, 0, 1);
     if (rc) return rc;
-    rc = launch_median(r, ws.sres, ws.sflags, ws.smed, 0, 0, 1, (size_t)Wn, ws.segC_start, ws.segC_len, Wn, G, 1);
+    rc = launch_median(r, ws.sres, ws.sflags, ws.smed, 0, 0, 1, (size_t)Wn, ws.segC_start, ws.segC_len, Wn, G, 1, pl.maxchunk);
     if (rc) return rc;
     rc = launch_colst(r, pl.swF, ws.sres, ws.smed, ws.sout, ws.d_chunk_ends, Fa, Wn, G, 0, 0, 1);
     if (rc) return rc;
@@ -1920,7 +2142,7 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
     // contiguous rows of the FT layout; flags = input | spectral flags.
     rc = launch_transpose<uint8_t>(r, ws.flagsTF, ws.flagsFT, T, Fa, N, N, W);
     if (rc) return rc;
-    rc = launch_median(r, residFT, ws.flagsFT, ws.med, wsB, N, (size_t)T, 1, ws.segT_start, ws.segT_len, Fa, 1, W);
+    rc = launch_median(r, residFT, ws.flagsFT, ws.med, wsB, N, (size_t)T, 1, ws.segT_start, ws.segT_len, Fa, 1, W, pl.T);
     if (rc) return rc;
     rc = launch_colst(r, pl.swT, residTF, ws.med, ws.tflTF, ws.d_tends, T, Fa, 1, N, N, W);
     if (rc) return rc;
@@ -1929,7 +2151,7 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
     // MAD per (time, chunk) = contiguous row segments of the TF layout.
     rc = launch_u8<1>(r, ws.tflTF, ws.flagsTF, N, N, N, W);
     if (rc) return rc;
-    rc = launch_median(r, residTF, ws.flagsTF, ws.med, N, N, (size_t)Fa, 1, ws.segC_start, ws.segC_len, T, G, W);
+    rc = launch_median(r, residTF, ws.flagsTF, ws.med, N, N, (size_t)Fa, 1, ws.segC_start, ws.segC_len, T, G, W, pl.maxchunk);
     if (rc) return rc;
     rc = launch_colst(r, pl.swF, residFT, ws.med, ws.fflFT, ws.d_chunk_ends, Fa, T, G, wsB, N, W);
     if (rc) return rc;
@@ -2181,5 +2403,54 @@ extern "C" int tri_bench_sumthreshold(const float* data, const double* mad, uint
     (void)hipFree(ring);
     (void)hipFree(acc);
     (void)hipFree(d_ends);
+    return TRI_OK;
+}
+
+// Test hook: exact segmented medians of |x| over unflagged samples of a
+// [n_win][rows][row_len] array; segments [ends[g], ends[g+1]) along each row.
+// variant: 0 = automatic choice, 1 = wave kernel (segments <= 1024),
+// 2 = workgroup kernel with scalar loads, 3 = workgroup kernel with vector
+// loads (needs row_len, segment bounds % 4 == 0).  med: [n_win][rows][G].
+extern "C" int tri_test_median(const float* data, const uint8_t* flags, double* med,
+                               int64_t n_win, int64_t rows, int64_t row_len,
+                               const int64_t* seg_ends, int64_t n_seg_ends, int variant,
+                               void* stream) {
+    if (!data || !flags || !med || !seg_ends || n_seg_ends < 2 || n_win <= 0 || rows <= 0)
+        return set_err(TRI_EINVAL, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    int G = (int)n_seg_ends - 1;
+    std::vector<int64_t> start(G), len(G);
+    int64_t maxlen = 0;
+    bool al4 = row_len % 4 == 0;
+    for (int g = 0; g < G; g++) {
+        start[g] = seg_ends[g];
+        len[g] = seg_ends[g + 1] - seg_ends[g];
+        if (len[g] < 0 || seg_ends[g] < 0 || seg_ends[g + 1] > row_len) return set_err(TRI_EINVAL, "bad segment");
+        maxlen = std::max(maxlen, len[g]);
+        al4 = al4 && start[g] % 4 == 0 && len[g] % 4 == 0;
+    }
+    int64_t *d_start = nullptr, *d_len = nullptr;
+    HIPCHK(hipMalloc(&d_start, G * sizeof(int64_t)));
+    HIPCHK(hipMalloc(&d_len, G * sizeof(int64_t)));
+    HIPCHK(hipMemcpy(d_start, start.data(), G * sizeof(int64_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_len, len.data(), G * sizeof(int64_t), hipMemcpyHostToDevice));
+    size_t WS = (size_t)rows * row_len, RS = (size_t)row_len;
+    int R = (int)rows;
+    if (variant == 0) variant = maxlen <= 64 * MW_K ? 1 : (al4 ? 3 : 2);
+    if (variant == 1 && maxlen > 64 * MW_K) return set_err(TRI_EINVAL, "wave kernel handles segments <= 1024");
+    if (variant == 3 && !al4) return set_err(TRI_EINVAL, "vector loads need 4-aligned segments");
+    if (variant == 1)
+        hipLaunchKernelGGL(k_median_wave, dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)n_win), dim3(256), 0, st,
+                           data, flags, med, WS, WS, RS, (size_t)1, d_start, d_len, R, G);
+    else if (variant == 3)
+        hipLaunchKernelGGL(k_median<true>, dim3((unsigned)(R * G), (unsigned)n_win), dim3(256), 0, st, data, flags,
+                           med, WS, WS, RS, (size_t)1, d_start, d_len, R, G);
+    else
+        hipLaunchKernelGGL(k_median<false>, dim3((unsigned)(R * G), (unsigned)n_win), dim3(256), 0, st, data, flags,
+                           med, WS, WS, RS, (size_t)1, d_start, d_len, R, G);
+    LAUNCHCHK();
+    HIPCHK(hipStreamSynchronize(st));
+    (void)hipFree(d_start);
+    (void)hipFree(d_len);
     return TRI_OK;
 }
