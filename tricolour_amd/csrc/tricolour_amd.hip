@@ -137,9 +137,12 @@ __global__ void k_abs_c64(const float2* __restrict__ z, float* __restrict__ out,
 // K2  batched tiled transpose  src[W][R][C] -> dst[W][C][R]  (64x64 LDS tile)
 // grid (ceil(C/64), ceil(R/64), W), block (64,4)
 // ---------------------------------------------------------------------------
+// `denom` != 0 (float images only): the stored value is x / denom -- the
+// final division of _box_gaussian_filter1d (flagging.py:419), deferred from
+// the latency-bound sequential filter kernel to this bandwidth-bound copy.
 template <typename T>
 __global__ void k_transpose(const T* __restrict__ src, T* __restrict__ dst, int R, int C,
-                            size_t src_ws, size_t dst_ws) {
+                            size_t src_ws, size_t dst_ws, float denom) {
     __shared__ T tile[64][65];
     const T* s = src + (size_t)blockIdx.z * src_ws;
     T* d = dst + (size_t)blockIdx.z * dst_ws;
@@ -152,7 +155,11 @@ __global__ void k_transpose(const T* __restrict__ src, T* __restrict__ dst, int 
     __syncthreads();
     for (int j = ty; j < 64; j += 4) {
         int c = c0 + j, r = r0 + tx;
-        if (r < R && c < C) d[(size_t)c * R + r] = tile[tx][j];
+        if (r < R && c < C) {
+            T v = tile[tx][j];
+            if (sizeof(T) == 4 && denom != 0.0f) v = (T)((float)v / denom);
+            d[(size_t)c * R + r] = v;
+        }
     }
 }
 
@@ -620,7 +627,7 @@ k_colfilter(float* __restrict__ bufW, float* __restrict__ bufO,
 // the four float64 chains of a step are independent.
 // grid (ceil(C/BT), W, 2 images), block BT, dynamic LDS 4 * 2r * BT floats
 // ---------------------------------------------------------------------------
-template <int SRCMODE>
+template <int SRCMODE, bool DIV>
 __global__ void __launch_bounds__(256)
 k_colfilter_lds(const float* __restrict__ srcW, const float* __restrict__ srcO,
                 const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags,
@@ -654,12 +661,81 @@ k_colfilter_lds(const float* __restrict__ srcW, const float* __restrict__ srcO,
     float o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;       // stage outputs of the previous step
     int slot1 = 0, slot2 = 0, slot3 = 0, slot4 = 0;
     const int total = n + 4 * r + 3;
-    constexpr int PF = 8;
-    float pre[PF];
+    // Deep prefetch: with the LDS rings capping occupancy at 2 waves / SIMD,
+    // bytes in flight (Little's law against ~2 us of HBM latency) come from
+    // per-thread loads, not from thread count.
+    constexpr int PF = 32;
+    float pre[PF], cur[PF];
 #pragma unroll
     for (int u = 0; u < PF; u++) pre[u] = (u < n) ? load(u) : 0.0f;
+
+    // One cascade step.  FAST = every stage is inside its steady range
+    // (4r + 3 <= m, m < n): no bounds tests, so the four float64 chains of a
+    // step are straight-line code the scheduler can interleave.
+    // Ring reads are issued one step ahead (R2 >= 2, so the slot read for step
+    // m + 1 differs from the slot written at step m): their LDS latency hides
+    // behind the arithmetic of the current step instead of stalling each stage.
+    float* rp1 = ring;
+    float* rp2 = ring + (size_t)(1 * R2) * BT;
+    float* rp3 = ring + (size_t)(2 * R2) * BT;
+    float* rp4 = ring + (size_t)(3 * R2) * BT;
+    float old1 = 0.0f, old2 = 0.0f, old3 = 0.0f, old4 = 0.0f;   // rings start zeroed
+    auto nextslot = [&](int sl) { return (sl + 1 == R2) ? 0 : sl + 1; };
+
+    auto step = [&](auto fastc, const int m, const float xin) {
+        constexpr bool FAST = decltype(fastc)::value;
+        const bool a4 = FAST || (m - 3 >= 0 && m - 3 < n + 4 * r);
+        const bool a3 = FAST || (m - 2 >= 0 && m - 2 < n + 4 * r);
+        const bool a2 = FAST || (m - 1 >= 0 && m - 1 < n + 4 * r);
+        const bool a1 = FAST || (m < n + R2);
+        const int ns1 = a1 ? nextslot(slot1) : slot1, ns2 = a2 ? nextslot(slot2) : slot2;
+        const int ns3 = a3 ? nextslot(slot3) : slot3, ns4 = a4 ? nextslot(slot4) : slot4;
+        // prefetch next step's trailing samples
+        const float nold1 = rp1[(size_t)ns1 * BT], nold2 = rp2[(size_t)ns2 * BT];
+        const float nold3 = rp3[(size_t)ns3 * BT], nold4 = rp4[(size_t)ns4 * BT];
+        // stage 4 (time t4 = m - 3): input out_3[t4], present for 2r <= t4 < n + 4r
+        if (a4) {
+            const int t = m - 3;
+            float in = (FAST || t >= R2) ? o3 : 0.0f;
+            rp4[(size_t)slot4 * BT] = in;
+            s4 += (double)in;
+            float out = (float)s4;
+            s4 -= (double)old4;
+            int i = t - 4 * r;
+            if (FAST || i >= 0) dst[(size_t)i * Cs] = DIV ? out / denom : out;
+        }
+        // stage 3 (t3 = m - 2): input out_2[t3], t3 in [0, n + 4r)
+        if (a3) {
+            float in = o2;
+            rp3[(size_t)slot3 * BT] = in;
+            s3 += (double)in;
+            o3 = (float)s3;
+            s3 -= (double)old3;
+        }
+        // stage 2 (t2 = m - 1): input out_1[t2] for t2 < n + 2r, then drains to n + 4r
+        if (a2) {
+            float in = (FAST || m - 1 < n + R2) ? o1 : 0.0f;
+            rp2[(size_t)slot2 * BT] = in;
+            s2 += (double)in;
+            o2 = (float)s2;
+            s2 -= (double)old2;
+        }
+        // stage 1 (t1 = m): input data[t1] for t1 < n, drains to n + 2r
+        if (a1) {
+            float in = (FAST || m < n) ? xin : 0.0f;
+            rp1[(size_t)slot1 * BT] = in;
+            s1 += (double)in;
+            o1 = (float)s1;
+            s1 -= (double)old1;
+        }
+        // a stage that did not run keeps its pending trailing sample
+        if (a1) { old1 = nold1; slot1 = ns1; }
+        if (a2) { old2 = nold2; slot2 = ns2; }
+        if (a3) { old3 = nold3; slot3 = ns3; }
+        if (a4) { old4 = nold4; slot4 = ns4; }
+    };
+
     for (int m0 = 0; m0 < total; m0 += PF) {
-        float cur[PF];
 #pragma unroll
         for (int u = 0; u < PF; u++) cur[u] = pre[u];
 #pragma unroll
@@ -667,67 +743,12 @@ k_colfilter_lds(const float* __restrict__ srcW, const float* __restrict__ srcO,
             int t = m0 + PF + u;
             pre[u] = (t < n) ? load(t) : 0.0f;
         }
+        if (m0 >= 4 * r + 3 && m0 + PF <= n) {
 #pragma unroll
-        for (int u = 0; u < PF; u++) {
-            const int m = m0 + u;
-            // stage 4 (time t4 = m - 3): input out_3[t4], present for 2r <= t4 < n + 4r
-            {
-                const int t = m - 3;
-                if (t >= 0 && t < n + 4 * r) {
-                    float in = (t >= R2) ? o3 : 0.0f;
-                    float* rp = ring + (size_t)(3 * R2 + slot4) * BT;
-                    float old = *rp;
-                    *rp = in;
-                    if (++slot4 == R2) slot4 = 0;
-                    s4 += (double)in;
-                    float out = (float)s4;
-                    s4 -= (double)old;
-                    int i = t - 4 * r;
-                    if (i >= 0) dst[(size_t)i * Cs] = out / denom;
-                }
-            }
-            // stage 3 (t3 = m - 2): input out_2[t3], t3 in [0, n + 4r)
-            {
-                const int t = m - 2;
-                if (t >= 0 && t < n + 4 * r) {
-                    float in = o2;
-                    float* rp = ring + (size_t)(2 * R2 + slot3) * BT;
-                    float old = *rp;
-                    *rp = in;
-                    if (++slot3 == R2) slot3 = 0;
-                    s3 += (double)in;
-                    o3 = (float)s3;
-                    s3 -= (double)old;
-                }
-            }
-            // stage 2 (t2 = m - 1): input out_1[t2] for t2 < n + 2r, then drains to n + 4r
-            {
-                const int t = m - 1;
-                if (t >= 0 && t < n + 4 * r) {
-                    float in = (t < n + R2) ? o1 : 0.0f;
-                    float* rp = ring + (size_t)(1 * R2 + slot2) * BT;
-                    float old = *rp;
-                    *rp = in;
-                    if (++slot2 == R2) slot2 = 0;
-                    s2 += (double)in;
-                    o2 = (float)s2;
-                    s2 -= (double)old;
-                }
-            }
-            // stage 1 (t1 = m): input data[t1] for t1 < n, drains to n + 2r
-            {
-                const int t = m;
-                if (t < n + R2) {
-                    float in = (t < n) ? cur[u] : 0.0f;
-                    float* rp = ring + (size_t)slot1 * BT;
-                    float old = *rp;
-                    *rp = in;
-                    if (++slot1 == R2) slot1 = 0;
-                    s1 += (double)in;
-                    o1 = (float)s1;
-                    s1 -= (double)old;
-                }
-            }
+            for (int u = 0; u < PF; u++) step(std::true_type{}, m0 + u, cur[u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < PF; u++) step(std::false_type{}, m0 + u, cur[u]);
         }
     }
 }
@@ -767,12 +788,13 @@ __global__ void k_build_wo4(const float* __restrict__ data, const uint8_t* __res
 template <int MODE>
 __global__ void k_masked_div(const float* __restrict__ w, float* __restrict__ o,
                              const float* __restrict__ data, size_t nper, size_t ws_wo,
-                             size_t ws_data) {
+                             size_t ws_data, float denom) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nper) return;
     size_t win = blockIdx.y;
     float wv = w[win * ws_wo + i];
     float ov = o[win * ws_wo + i];
+    if (denom != 0.0f) { wv = wv / denom; ov = ov / denom; }   // deferred flagging.py:419
     float bg = (wv == 0.0f) ? NAN : ov / wv;
     if (MODE == 1) bg = fabsf(data[win * ws_data + i] - bg);
     o[win * ws_wo + i] = bg;
@@ -1407,13 +1429,18 @@ __global__ void k_final16(const uint8_t* __restrict__ dil, const int* __restrict
 
 template <int MODE>
 __global__ void k_masked_div4(const float* __restrict__ w, float* __restrict__ o,
-                              const float* __restrict__ data, size_t n4per, size_t ws_wo, size_t ws_data) {
+                              const float* __restrict__ data, size_t n4per, size_t ws_wo, size_t ws_data,
+                              float denom) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4per) return;
     size_t win = blockIdx.y;
     float4 wv = reinterpret_cast<const float4*>(w + win * ws_wo)[i];
     float4* po = reinterpret_cast<float4*>(o + win * ws_wo) + i;
     float4 ov = *po;
+    if (denom != 0.0f) {   // deferred flagging.py:419
+        wv = make_float4(wv.x / denom, wv.y / denom, wv.z / denom, wv.w / denom);
+        ov = make_float4(ov.x / denom, ov.y / denom, ov.z / denom, ov.w / denom);
+    }
     float bg[4] = {(wv.x == 0.0f) ? NAN : ov.x / wv.x, (wv.y == 0.0f) ? NAN : ov.y / wv.y,
                    (wv.z == 0.0f) ? NAN : ov.z / wv.z, (wv.w == 0.0f) ? NAN : ov.w / wv.w};
     if (MODE == 1) {
@@ -1853,25 +1880,34 @@ int colfilter_lds_block(int rad, int C) {
 //   srcmode 1: images are float arrays; for the multi-pass kernel they sit in
 //              rows [4r, 4r+n) of bufW / bufO, for the LDS kernel in rows [0,n)
 // Output: rows [0,n) of dstW / dstO.
+// `deferred_denom` (optional): when the single-sweep kernel is used the final
+// division by float32(d)**4 is left to the consumer (transpose / masked_div) and
+// *deferred_denom receives the denominator; otherwise it is set to 0.
 int launch_colfilter(const Run& r, int srcmode, float* bufW, float* bufO, const float* srcData,
                      const uint8_t* srcFlags, float* dstW, float* dstO, int n, int C, int rad,
-                     size_t bws, size_t sws, size_t dws, int64_t W) {
+                     size_t bws, size_t sws, size_t dws, int64_t W, float* deferred_denom = nullptr) {
     float denom = box_denominator(rad);
     int bt = colfilter_lds_block(rad, C);
+    if (deferred_denom) *deferred_denom = 0.0f;
     if (bt > 0) {
         size_t lds = (size_t)4 * 2 * rad * bt * sizeof(float);
         dim3 grid((unsigned)cdiv(C, bt), (unsigned)W, 2);
         static bool attr_set = false;
         if (!attr_set) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_set = true;
         }
         if (srcmode == 0)
-            hipLaunchKernelGGL(k_colfilter_lds<0>, grid, dim3(bt), lds, r.st, (const float*)nullptr, (const float*)nullptr,
+            hipLaunchKernelGGL((k_colfilter_lds<0, true>), grid, dim3(bt), lds, r.st, (const float*)nullptr, (const float*)nullptr,
                                srcData, srcFlags, dstW, dstO, n, C, rad, denom, (size_t)0, sws, dws);
-        else
-            hipLaunchKernelGGL(k_colfilter_lds<1>, grid, dim3(bt), lds, r.st, (const float*)bufW, (const float*)bufO,
+        else if (deferred_denom) {
+            *deferred_denom = denom;
+            hipLaunchKernelGGL((k_colfilter_lds<1, false>), grid, dim3(bt), lds, r.st, (const float*)bufW, (const float*)bufO,
+                               srcData, srcFlags, dstW, dstO, n, C, rad, denom, bws, sws, dws);
+        } else
+            hipLaunchKernelGGL((k_colfilter_lds<1, true>), grid, dim3(bt), lds, r.st, (const float*)bufW, (const float*)bufO,
                                srcData, srcFlags, dstW, dstO, n, C, rad, denom, bws, sws, dws);
         LAUNCHCHK();
         return TRI_OK;
@@ -1909,7 +1945,7 @@ int launch_colst(const Run& r, const StWin& sw, const float* data, const double*
 
 template <typename T>
 int launch_transpose(const Run& r, const T* src, T* dst, int R, int C, size_t sws, size_t dws,
-                     int64_t W) {
+                     int64_t W, float denom = 0.0f) {
     dim3 grid((unsigned)cdiv(C, 64), (unsigned)cdiv(R, 64), (unsigned)W);
     if (sizeof(T) == 1 && R % 4 == 0 && C % 4 == 0 && sws % 4 == 0 && dws % 4 == 0 &&
         ((uintptr_t)src % 4 == 0) && ((uintptr_t)dst % 4 == 0)) {
@@ -1917,7 +1953,7 @@ int launch_transpose(const Run& r, const T* src, T* dst, int R, int C, size_t sw
         LAUNCHCHK();
         return TRI_OK;
     }
-    hipLaunchKernelGGL(k_transpose<T>, grid, dim3(64, 4), 0, r.st, src, dst, R, C, sws, dws);
+    hipLaunchKernelGGL(k_transpose<T>, grid, dim3(64, 4), 0, r.st, src, dst, R, C, sws, dws, denom);
     LAUNCHCHK();
     return TRI_OK;
 }
@@ -1942,11 +1978,11 @@ int launch_u8(const Run& r, const uint8_t* a, uint8_t* b, size_t nper, size_t ws
 }
 
 template <int MODE>
-int launch_masked_div(const Run& r, const float* w, float* o, const float* data, size_t nper, size_t ws_wo, size_t ws_data, int64_t W) {
+int launch_masked_div(const Run& r, const float* w, float* o, const float* data, size_t nper, size_t ws_wo, size_t ws_data, int64_t W, float denom = 0.0f) {
     if (nper % 4 == 0 && ws_wo % 4 == 0 && ws_data % 4 == 0 && ((uintptr_t)w % 16 == 0) && ((uintptr_t)o % 16 == 0))
-        hipLaunchKernelGGL(k_masked_div4<MODE>, grid1(nper / 4, W), dim3(256), 0, r.st, w, o, data, nper / 4, ws_wo, ws_data);
+        hipLaunchKernelGGL(k_masked_div4<MODE>, grid1(nper / 4, W), dim3(256), 0, r.st, w, o, data, nper / 4, ws_wo, ws_data, denom);
     else
-        hipLaunchKernelGGL(k_masked_div<MODE>, grid1(nper, W), dim3(256), 0, r.st, w, o, data, nper, ws_wo, ws_data);
+        hipLaunchKernelGGL(k_masked_div<MODE>, grid1(nper, W), dim3(256), 0, r.st, w, o, data, nper, ws_wo, ws_data, denom);
     LAUNCHCHK();
     return TRI_OK;
 }
@@ -2024,13 +2060,14 @@ int background2d(const Run& r) {
         // streaming float images through the sequential kernel is faster than
         // byte loads of the flags inside its per-line loop.
         static const bool prebuild = [] { const char* e = getenv("TRI_TIME_PREBUILD"); return !(e && e[0] == '0'); }();
+        float den_t = 0.0f, den_f = 0.0f;   // divisions deferred to the transposes / masked_div
         if (r0 > 0 && prebuild && colfilter_lds_block(r0, Fa) > 0) {
             if (N % 4 == 0 && wsA % 4 == 0)
                 hipLaunchKernelGGL(k_build_wo4, grid1(N / 4, W), dim3(256), 0, r.st, ws.dataTF, ws.bgfTF, ws.Aw, ws.Ao, N / 4, N, wsA);
             else
                 hipLaunchKernelGGL(k_build_wo, grid1(N, W), dim3(256), 0, r.st, ws.dataTF, ws.bgfTF, ws.Aw, ws.Ao, N, N, wsA);
             LAUNCHCHK();
-            rc = launch_colfilter(r, 1, ws.Aw, ws.Ao, nullptr, nullptr, ws.Aw, ws.Ao, T, Fa, r0, wsA, 0, wsA, W);
+            rc = launch_colfilter(r, 1, ws.Aw, ws.Ao, nullptr, nullptr, ws.Aw, ws.Ao, T, Fa, r0, wsA, 0, wsA, W, &den_t);
             if (rc) return rc;
         } else if (r0 > 0) {
             rc = launch_colfilter(r, 0, ws.Aw, ws.Ao, ws.dataTF, ws.bgfTF, ws.Aw, ws.Ao, T, Fa, r0, wsA, N, wsA, W);
@@ -2042,20 +2079,20 @@ int background2d(const Run& r) {
         // --- to FT layout: rows [4 r1, 4 r1 + Fa) of the padded buffers for the
         //     in-place multi-pass filter, rows [0, Fa) for the single-sweep one ---
         size_t off = colfilter_lds_block(r1, T) > 0 ? 0 : (size_t)4 * r1 * T;
-        rc = launch_transpose<float>(r, ws.Aw, ws.Bw + off, T, Fa, wsA, wsB, W);
+        rc = launch_transpose<float>(r, ws.Aw, ws.Bw + off, T, Fa, wsA, wsB, W, den_t);
         if (rc) return rc;
-        rc = launch_transpose<float>(r, ws.Ao, ws.Bo + off, T, Fa, wsA, wsB, W);
+        rc = launch_transpose<float>(r, ws.Ao, ws.Bo + off, T, Fa, wsA, wsB, W, den_t);
         if (rc) return rc;
         // --- frequency axis (FT layout: line = channel, column = time) ---
         if (r1 > 0) {
-            rc = launch_colfilter(r, 1, ws.Bw, ws.Bo, nullptr, nullptr, ws.Bw, ws.Bo, Fa, T, r1, wsB, 0, wsB, W);
+            rc = launch_colfilter(r, 1, ws.Bw, ws.Bo, nullptr, nullptr, ws.Bw, ws.Bo, Fa, T, r1, wsB, 0, wsB, W, &den_f);
             if (rc) return rc;
         }
         if (final_pass) {
-            rc = launch_masked_div<0>(r, ws.Bw, ws.Bo, ws.dataFT, N, wsB, N, W);
+            rc = launch_masked_div<0>(r, ws.Bw, ws.Bo, ws.dataFT, N, wsB, N, W, den_f);
             if (rc) return rc;
         } else {
-            rc = launch_masked_div<1>(r, ws.Bw, ws.Bo, ws.dataFT, N, wsB, N, W);
+            rc = launch_masked_div<1>(r, ws.Bw, ws.Bo, ws.dataFT, N, wsB, N, W, den_f);
             if (rc) return rc;
             // block medians over (all times) x (chunk channels): contiguous in FT
             rc = launch_median(r, ws.Bo, ws.bgfFT, ws.med, wsB, N, 0, 1, ws.segB_start, ws.segB_len, 1, G, W, pl.maxchunk * pl.T,
