@@ -627,7 +627,7 @@ k_colfilter(float* __restrict__ bufW, float* __restrict__ bufO,
 // the four float64 chains of a step are independent.
 // grid (ceil(C/BT), W, 2 images), block BT, dynamic LDS 4 * 2r * BT floats
 // ---------------------------------------------------------------------------
-template <int SRCMODE, bool DIV>
+template <int SRCMODE, bool DIV, bool TOUT>
 __global__ void __launch_bounds__(256)
 k_colfilter_lds(const float* __restrict__ srcW, const float* __restrict__ srcO,
                 const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags,
@@ -644,7 +644,11 @@ k_colfilter_lds(const float* __restrict__ srcW, const float* __restrict__ srcO,
     const float* src = SRCMODE == 1 ? ((img == 0 ? srcW : srcO) + win * sws_img + c) : nullptr;
     const float* sd = SRCMODE == 0 ? srcData + win * sws + c : nullptr;
     const uint8_t* sf = SRCMODE == 0 ? srcFlags + win * sws + c : nullptr;
-    float* dst = (img == 0 ? dstW : dstO) + win * dws + c;
+    // TOUT: the output is written TRANSPOSED -- line c becomes row c of an
+    // [C][n] image (n % 4 == 0) -- four consecutive outputs per 16-byte store,
+    // so the frequency-axis stage can consume it without a transpose pass.
+    float* dst = (img == 0 ? dstW : dstO) + win * dws + (TOUT ? (size_t)c * n : (size_t)c);
+    float tacc0 = 0.0f, tacc1 = 0.0f, tacc2 = 0.0f;
     float* ring = cf_ring + threadIdx.x;            // element (p, slot) at ((p*R2)+slot)*BT
     for (int k = 0; k < 4 * R2; k++) ring[(size_t)k * BT] = 0.0f;
 
@@ -702,7 +706,18 @@ k_colfilter_lds(const float* __restrict__ srcW, const float* __restrict__ srcO,
             float out = (float)s4;
             s4 -= (double)old4;
             int i = t - 4 * r;
-            if (FAST || i >= 0) dst[(size_t)i * Cs] = DIV ? out / denom : out;
+            if (FAST || i >= 0) {
+                float y = DIV ? out / denom : out;
+                if (TOUT) {
+                    const int ph = i & 3;
+                    if (ph == 0) tacc0 = y;
+                    else if (ph == 1) tacc1 = y;
+                    else if (ph == 2) tacc2 = y;
+                    else *reinterpret_cast<float4*>(dst + (i - 3)) = make_float4(tacc0, tacc1, tacc2, y);
+                } else {
+                    dst[(size_t)i * Cs] = y;
+                }
+            }
         }
         // stage 3 (t3 = m - 2): input out_2[t3], t3 in [0, n + 4r)
         if (a3) {
@@ -1885,7 +1900,8 @@ int colfilter_lds_block(int rad, int C) {
 // *deferred_denom receives the denominator; otherwise it is set to 0.
 int launch_colfilter(const Run& r, int srcmode, float* bufW, float* bufO, const float* srcData,
                      const uint8_t* srcFlags, float* dstW, float* dstO, int n, int C, int rad,
-                     size_t bws, size_t sws, size_t dws, int64_t W, float* deferred_denom = nullptr) {
+                     size_t bws, size_t sws, size_t dws, int64_t W, float* deferred_denom = nullptr,
+                     bool transposed_out = false) {
     float denom = box_denominator(rad);
     int bt = colfilter_lds_block(rad, C);
     if (deferred_denom) *deferred_denom = 0.0f;
@@ -1894,20 +1910,24 @@ int launch_colfilter(const Run& r, int srcmode, float* bufW, float* bufO, const 
         dim3 grid((unsigned)cdiv(C, bt), (unsigned)W, 2);
         static bool attr_set = false;
         if (!attr_set) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<0, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<1, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<1, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_set = true;
         }
-        if (srcmode == 0)
-            hipLaunchKernelGGL((k_colfilter_lds<0, true>), grid, dim3(bt), lds, r.st, (const float*)nullptr, (const float*)nullptr,
+        if (transposed_out)
+            hipLaunchKernelGGL((k_colfilter_lds<1, true, true>), grid, dim3(bt), lds, r.st, (const float*)bufW, (const float*)bufO,
+                               srcData, srcFlags, dstW, dstO, n, C, rad, denom, bws, sws, dws);
+        else if (srcmode == 0)
+            hipLaunchKernelGGL((k_colfilter_lds<0, true, false>), grid, dim3(bt), lds, r.st, (const float*)nullptr, (const float*)nullptr,
                                srcData, srcFlags, dstW, dstO, n, C, rad, denom, (size_t)0, sws, dws);
         else if (deferred_denom) {
             *deferred_denom = denom;
-            hipLaunchKernelGGL((k_colfilter_lds<1, false>), grid, dim3(bt), lds, r.st, (const float*)bufW, (const float*)bufO,
+            hipLaunchKernelGGL((k_colfilter_lds<1, false, false>), grid, dim3(bt), lds, r.st, (const float*)bufW, (const float*)bufO,
                                srcData, srcFlags, dstW, dstO, n, C, rad, denom, bws, sws, dws);
         } else
-            hipLaunchKernelGGL((k_colfilter_lds<1, true>), grid, dim3(bt), lds, r.st, (const float*)bufW, (const float*)bufO,
+            hipLaunchKernelGGL((k_colfilter_lds<1, true, false>), grid, dim3(bt), lds, r.st, (const float*)bufW, (const float*)bufO,
                                srcData, srcFlags, dstW, dstO, n, C, rad, denom, bws, sws, dws);
         LAUNCHCHK();
         return TRI_OK;
@@ -2061,13 +2081,25 @@ int background2d(const Run& r) {
         // byte loads of the flags inside its per-line loop.
         static const bool prebuild = [] { const char* e = getenv("TRI_TIME_PREBUILD"); return !(e && e[0] == '0'); }();
         float den_t = 0.0f, den_f = 0.0f;   // divisions deferred to the transposes / masked_div
+        bool direct_ft = false;
         if (r0 > 0 && prebuild && colfilter_lds_block(r0, Fa) > 0) {
             if (N % 4 == 0 && wsA % 4 == 0)
                 hipLaunchKernelGGL(k_build_wo4, grid1(N / 4, W), dim3(256), 0, r.st, ws.dataTF, ws.bgfTF, ws.Aw, ws.Ao, N / 4, N, wsA);
             else
                 hipLaunchKernelGGL(k_build_wo, grid1(N, W), dim3(256), 0, r.st, ws.dataTF, ws.bgfTF, ws.Aw, ws.Ao, N, N, wsA);
             LAUNCHCHK();
-            rc = launch_colfilter(r, 1, ws.Aw, ws.Ao, nullptr, nullptr, ws.Aw, ws.Ao, T, Fa, r0, wsA, 0, wsA, W, &den_t);
+            // prebuilt TF images in, filtered images out -- directly in FT layout
+            // (into the rows the frequency-axis stage expects) when T % 4 == 0
+            // (measured: the scattered 16-byte stores cost as much as the two
+            //  transposes they replace, so this is opt-in: TRI_FILTER_DIRECT_FT=1)
+            static const bool want_direct = [] { const char* e = getenv("TRI_FILTER_DIRECT_FT"); return e && e[0] == '1'; }();
+            direct_ft = want_direct && (T % 4 == 0) && (wsB % 4 == 0);
+            if (direct_ft) {
+                size_t off2 = colfilter_lds_block(r1, T) > 0 ? 0 : (size_t)4 * r1 * T;
+                rc = launch_colfilter(r, 1, ws.Aw, ws.Ao, nullptr, nullptr, ws.Bw + off2, ws.Bo + off2, T, Fa, r0, wsA, 0, wsB, W, nullptr, true);
+            } else {
+                rc = launch_colfilter(r, 1, ws.Aw, ws.Ao, nullptr, nullptr, ws.Aw, ws.Ao, T, Fa, r0, wsA, 0, wsA, W, &den_t);
+            }
             if (rc) return rc;
         } else if (r0 > 0) {
             rc = launch_colfilter(r, 0, ws.Aw, ws.Ao, ws.dataTF, ws.bgfTF, ws.Aw, ws.Ao, T, Fa, r0, wsA, N, wsA, W);
@@ -2079,10 +2111,12 @@ int background2d(const Run& r) {
         // --- to FT layout: rows [4 r1, 4 r1 + Fa) of the padded buffers for the
         //     in-place multi-pass filter, rows [0, Fa) for the single-sweep one ---
         size_t off = colfilter_lds_block(r1, T) > 0 ? 0 : (size_t)4 * r1 * T;
-        rc = launch_transpose<float>(r, ws.Aw, ws.Bw + off, T, Fa, wsA, wsB, W, den_t);
-        if (rc) return rc;
-        rc = launch_transpose<float>(r, ws.Ao, ws.Bo + off, T, Fa, wsA, wsB, W, den_t);
-        if (rc) return rc;
+        if (!direct_ft) {
+            rc = launch_transpose<float>(r, ws.Aw, ws.Bw + off, T, Fa, wsA, wsB, W, den_t);
+            if (rc) return rc;
+            rc = launch_transpose<float>(r, ws.Ao, ws.Bo + off, T, Fa, wsA, wsB, W, den_t);
+            if (rc) return rc;
+        }
         // --- frequency axis (FT layout: line = channel, column = time) ---
         if (r1 > 0) {
             rc = launch_colfilter(r, 1, ws.Bw, ws.Bo, nullptr, nullptr, ws.Bw, ws.Bo, Fa, T, r1, wsB, 0, wsB, W, &den_f);
