@@ -1037,8 +1037,11 @@ struct StFusedArgs {
     double tf[4];   // rho ** log2(w)
 };
 
+#ifndef ST_WAVES
+#define ST_WAVES 2
+#endif
 template <int W0, int W1, int W2, int W3>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, ST_WAVES)
 k_colst_fused(const float* __restrict__ data, const double* __restrict__ med,
               uint8_t* __restrict__ out, const int64_t* __restrict__ chunk_ends,
               StFusedArgs fa, double thr_scale, int L, int C, int G, size_t ws_data,
@@ -1047,10 +1050,12 @@ k_colst_fused(const float* __restrict__ data, const double* __restrict__ med,
     constexpr int D[4] = {0, W0, W0 + W1, W0 + W1 + W2};   // ingest delay of stage j
     constexpr int DOUT = W0 + W1 + W2 + W3 - 1;             // final flags lag the head by this
     constexpr int MAXW = W3;
+    constexpr int UN = 16;                                   // ticks per unrolled block
     static_assert(W0 <= W1 && W1 <= W2 && W2 <= W3 && W3 <= 8, "windows must be sorted, <= 8");
     static_assert((W0 & (W0 - 1)) == 0 && (W1 & (W1 - 1)) == 0 && (W2 & (W2 - 1)) == 0 &&
                   (W3 & (W3 - 1)) == 0, "power-of-two windows");
     static_assert(W0 + W1 + W2 <= 7, "sample ring is 8 deep");
+    static_assert(DOUT < UN, "flag ring is 16 deep");
 
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
@@ -1071,11 +1076,18 @@ k_colst_fused(const float* __restrict__ data, const double* __restrict__ med,
     x += (size_t)p0 * Cs;
     o += (size_t)p0 * Cs;
 
+    // thr = f64(thr0) / rho^log2(w) (flagging.py:643); T = thr * w (exact);
+    // lim = largest float32 <= thr, so that for a float32 sample xf
+    //   (double)xf > thr  <=>  xf > lim     and    (double)xf < -thr  <=>  xf < -lim
     double thr[4], T[4];
+    float lim[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         thr[j] = (double)thr0 / fa.tf[j];
         T[j] = thr[j] * (double)W[j];
+        float l = (float)thr[j];
+        if ((double)l > thr[j]) l = __uint_as_float(__float_as_uint(l) - 1u);   // thr > 0 here
+        lim[j] = l;
     }
     double cumlast[4] = {0.0, 0.0, 0.0, 0.0};
     double r0[W0], r1[W1], r2[W2], r3[W3];
@@ -1087,41 +1099,49 @@ k_colst_fused(const float* __restrict__ data, const double* __restrict__ med,
     for (int k = 0; k < W2; k++) r2[k] = 0.0;
 #pragma unroll
     for (int k = 0; k < W3; k++) r3[k] = 0.0;
-    unsigned hb[4] = {0, 0, 0, 0}, inb[4] = {0, 0, 0, 0};
-    unsigned hand[4] = {0, 0, 0, 0};   // flags emitted by stage j at the previous tick (bit0 pos, bit16 neg)
-    double xr[8];
+    // ticks since the last positive / negative hit of stage j (>= w: none in reach)
+    int sp[4] = {W0, W1, W2, W3}, sn[4] = {W0, W1, W2, W3};
+    // accumulated flags by position (mod 16): stage j ORs its dilated hits in,
+    // stage j+1 reads them for its clamp, the last stage's position is output
+    unsigned accP[UN], accN[UN];
 #pragma unroll
-    for (int k = 0; k < 8; k++) xr[k] = 0.0;
+    for (int k = 0; k < UN; k++) { accP[k] = 0; accN[k] = 0; }
+    float xf[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) xf[k] = 0.0f;
 
     const int nticks = Lp + DOUT;
-    float cur[8], nxt[8];
+    float cur[UN];
 #pragma unroll
-    for (int u = 0; u < 8; u++) cur[u] = (u < Lp) ? x[(size_t)u * Cs] : 0.0f;
+    for (int u = 0; u < UN; u++) cur[u] = (u < Lp) ? x[(size_t)u * Cs] : 0.0f;
 
     auto block = [&](auto fastc, const int base) {
         constexpr bool fast = decltype(fastc)::value;
 #pragma unroll
-        for (int PH = 0; PH < 8; PH++) {
+        for (int PH = 0; PH < UN; PH++) {
             const int n = base + PH;
-            xr[PH] = (double)cur[PH];
-            unsigned outbits = 0;
-            // stages in reverse order: stage j consumes the hand-off of stage
-            // j-1 written at the previous tick before stage j-1 overwrites it
+            xf[PH & 7] = cur[PH];
+            // rolling prefetch: the slot just consumed is refilled 16 ticks ahead
+            cur[PH] = (n + UN < Lp) ? x[(size_t)(n + UN) * Cs] : 0.0f;
+            // stages in reverse order: stage j reads the flags stage j-1 wrote
+            // at the previous tick
 #pragma unroll
             for (int j = 3; j >= 0; j--) {
                 const int w = W[j];
-                const int i = n - D[j];
-                const int e = i + 1 - w;
-                const unsigned fin = (j == 0) ? 0u : hand[j - 1];
+                const int i = n - D[j];        // ingest position
+                const int e = i + 1 - w;       // emit position
                 const bool ing = fast || (i >= 0 && i < Lp);
                 const bool emi = fast || (e >= 0 && e < Lp);
                 bool hp = false, hn = false;
                 if (ing) {
-                    double xd = xr[(PH - D[j]) & 7];
-                    double cl = xd;
-                    if ((fin & 1u) && xd > thr[j]) cl = thr[j];
-                    else if ((fin & 0x10000u) && xd < -thr[j]) cl = -thr[j];
-                    double cum = cumlast[j] + cl;
+                    const float xs = xf[(PH - D[j]) & 7];
+                    double cl = (double)xs;
+                    if (j > 0) {
+                        const bool cp = (accP[(PH - D[j]) & (UN - 1)] != 0) && (xs > lim[j]);
+                        const bool cn = !cp && (accN[(PH - D[j]) & (UN - 1)] != 0) && (xs < -lim[j]);
+                        cl = cp ? thr[j] : (cn ? -thr[j] : cl);
+                    }
+                    const double cum = cumlast[j] + cl;
                     cumlast[j] = cum;
                     const int slot = (PH - D[j] + 1) & (w - 1);
                     double old;
@@ -1129,45 +1149,37 @@ k_colst_fused(const float* __restrict__ data, const double* __restrict__ med,
                     else if (j == 1) { old = r1[slot & (W1 - 1)]; r1[slot & (W1 - 1)] = cum; }
                     else if (j == 2) { old = r2[slot & (W2 - 1)]; r2[slot & (W2 - 1)] = cum; }
                     else { old = r3[slot & (W3 - 1)]; r3[slot & (W3 - 1)] = cum; }
-                    if (fast || e >= 0) {
-                        double S = cum - old;
-                        hp = S > T[j];
-                        hn = S < -T[j];
-                    }
+                    const double S = cum - old;
+                    const bool valid = fast || e >= 0;
+                    hp = valid && (S > T[j]);
+                    hn = valid && (S < -T[j]);
                 }
-                // both histories keep w bits per sign (pos in bits 0.., neg in
-                // bits 16..); the mask stops old pos bits leaking into the neg field
-                const unsigned m = (1u << w) - 1u;
-                const unsigned m2 = m | (m << 16);
                 if (emi) {
-                    hb[j] = ((hb[j] << 1) & m2) | (hp ? 1u : 0u) | (hn ? 0x10000u : 0u);
-                    inb[j] = ((inb[j] << 1) & m2) | (ing ? (fin & 0x10001u) : 0u);
-                    unsigned pout = ((inb[j] >> (w - 1)) & 1u) | ((hb[j] & m) ? 1u : 0u);
-                    unsigned nout = ((inb[j] >> (16 + w - 1)) & 1u) | ((hb[j] & (m << 16)) ? 1u : 0u);
-                    hand[j] = pout | (nout << 16);
-                    if (j == 3) outbits = pout | nout;
-                } else if (ing) {
-                    // positions before the first emit: keep the input-flag history moving
-                    inb[j] = ((inb[j] << 1) & m2) | (fin & 0x10001u);
+                    bool ap, an;
+                    if (w == 1) { ap = hp; an = hn; }
+                    else {
+                        sp[j] = hp ? 0 : sp[j] + 1;
+                        sn[j] = hn ? 0 : sn[j] + 1;
+                        ap = sp[j] < w;
+                        an = sn[j] < w;
+                    }
+                    const int es = (PH - D[j] + 1 - w) & (UN - 1);
+                    accP[es] = ap ? 1u : accP[es];
+                    accN[es] = an ? 1u : accN[es];
                 }
             }
             const int ef = n - DOUT;
-            if (fast || (ef >= o0 && ef < o1)) o[(size_t)ef * Cs] = (uint8_t)outbits;
+            const int fs = (PH - DOUT) & (UN - 1);
+            if (fast || (ef >= o0 && ef < o1)) o[(size_t)ef * Cs] = (uint8_t)(accP[fs] | accN[fs]);
+            accP[fs] = 0;
+            accN[fs] = 0;
         }
     };
 
-    for (int base = 0; base < nticks; base += 8) {
-        // prefetch the next block of samples
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            int n = base + 8 + u;
-            nxt[u] = (n < Lp) ? x[(size_t)n * Cs] : 0.0f;
-        }
-        const bool fast = base >= 16 && base + 7 < Lp && base - DOUT >= o0 && base + 7 - DOUT < o1;
+    for (int base = 0; base < nticks; base += UN) {
+        const bool fast = base >= UN && base + UN - 1 < Lp && base - DOUT >= o0 && base + UN - 1 - DOUT < o1;
         if (fast) block(std::true_type{}, base);
         else block(std::false_type{}, base);
-#pragma unroll
-        for (int u = 0; u < 8; u++) cur[u] = nxt[u];
     }
 }
 
