@@ -2094,18 +2094,20 @@ int background2d(const Run& r) {
         static const bool prebuild = [] { const char* e = getenv("TRI_TIME_PREBUILD"); return !(e && e[0] == '0'); }();
         float den_t = 0.0f, den_f = 0.0f;   // divisions deferred to the transposes / masked_div
         bool direct_ft = false;
+        // (for the in-place multi-pass kernel, used at large radii, building on
+        //  the fly measured faster: 11.4 vs 16.8 ms per call at 128 windows)
         if (r0 > 0 && prebuild && colfilter_lds_block(r0, Fa) > 0) {
+            const bool lds_path = true;
+            const size_t boff = lds_path ? 0 : (size_t)4 * r0 * Fa;
             if (N % 4 == 0 && wsA % 4 == 0)
-                hipLaunchKernelGGL(k_build_wo4, grid1(N / 4, W), dim3(256), 0, r.st, ws.dataTF, ws.bgfTF, ws.Aw, ws.Ao, N / 4, N, wsA);
+                hipLaunchKernelGGL(k_build_wo4, grid1(N / 4, W), dim3(256), 0, r.st, ws.dataTF, ws.bgfTF, ws.Aw + boff, ws.Ao + boff, N / 4, N, wsA);
             else
-                hipLaunchKernelGGL(k_build_wo, grid1(N, W), dim3(256), 0, r.st, ws.dataTF, ws.bgfTF, ws.Aw, ws.Ao, N, N, wsA);
+                hipLaunchKernelGGL(k_build_wo, grid1(N, W), dim3(256), 0, r.st, ws.dataTF, ws.bgfTF, ws.Aw + boff, ws.Ao + boff, N, N, wsA);
             LAUNCHCHK();
-            // prebuilt TF images in, filtered images out -- directly in FT layout
-            // (into the rows the frequency-axis stage expects) when T % 4 == 0
-            // (measured: the scattered 16-byte stores cost as much as the two
-            //  transposes they replace, so this is opt-in: TRI_FILTER_DIRECT_FT=1)
+            // (TRI_FILTER_DIRECT_FT=1: write the filtered images straight into FT
+            //  layout; measured no faster than the two transposes it replaces)
             static const bool want_direct = [] { const char* e = getenv("TRI_FILTER_DIRECT_FT"); return e && e[0] == '1'; }();
-            direct_ft = want_direct && (T % 4 == 0) && (wsB % 4 == 0);
+            direct_ft = lds_path && want_direct && (T % 4 == 0) && (wsB % 4 == 0);
             if (direct_ft) {
                 size_t off2 = colfilter_lds_block(r1, T) > 0 ? 0 : (size_t)4 * r1 * T;
                 rc = launch_colfilter(r, 1, ws.Aw, ws.Ao, nullptr, nullptr, ws.Bw + off2, ws.Bo + off2, T, Fa, r0, wsA, 0, wsB, W, nullptr, true);
