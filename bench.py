@@ -144,9 +144,21 @@ def roofline_sumthreshold(torch, device, T, F, kw):
                                               C.byref(ms), stream))
     samples = nwin * T * F
     achieved = samples * ST_BYTES_PER_SAMPLE / (ms.value * 1e-3) / 1e9
+    # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same
+    # launch geometry (FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE); bench.py
+    # cannot collect counters itself.
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_sumthreshold.json")))
+        if pmc.get("samples_per_launch") == samples:
+            traffic = pmc["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
     return dict(bound="hbm", kernel="k_colst (fused SumThreshold, all windows in one pass)",
                 achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                traffic_source="profiles/r01_pmc_sumthreshold.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+                algorithmic_bytes_per_launch=samples * ST_BYTES_PER_SAMPLE,
                 bytes_per_sample=ST_BYTES_PER_SAMPLE, samples_per_launch=samples,
                 ms_per_launch=round(ms.value, 4))
 
