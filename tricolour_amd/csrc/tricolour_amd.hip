@@ -1099,8 +1099,8 @@ k_colst_fused(const float* __restrict__ data, const double* __restrict__ med,
     for (int k = 0; k < W2; k++) r2[k] = 0.0;
 #pragma unroll
     for (int k = 0; k < W3; k++) r3[k] = 0.0;
-    // ticks since the last positive / negative hit of stage j (>= w: none in reach)
-    int sp[4] = {W0, W1, W2, W3}, sn[4] = {W0, W1, W2, W3};
+    // tick of the last positive / negative hit of stage j (far past: none in reach)
+    int sp[4] = {-64, -64, -64, -64}, sn[4] = {-64, -64, -64, -64};
     // accumulated flags by position (mod 16): stage j ORs its dilated hits in,
     // stage j+1 reads them for its clamp, the last stage's position is output
     unsigned accP[UN], accN[UN];
@@ -1127,6 +1127,9 @@ k_colst_fused(const float* __restrict__ data, const double* __restrict__ med,
             // at the previous tick
 #pragma unroll
             for (int j = 3; j >= 0; j--) {
+#ifdef ST_EXP_STAGES
+                if (j >= ST_EXP_STAGES) continue;
+#endif
                 const int w = W[j];
                 const int i = n - D[j];        // ingest position
                 const int e = i + 1 - w;       // emit position
@@ -1158,10 +1161,10 @@ k_colst_fused(const float* __restrict__ data, const double* __restrict__ med,
                     bool ap, an;
                     if (w == 1) { ap = hp; an = hn; }
                     else {
-                        sp[j] = hp ? 0 : sp[j] + 1;
-                        sn[j] = hn ? 0 : sn[j] + 1;
-                        ap = sp[j] < w;
-                        an = sn[j] < w;
+                        sp[j] = hp ? n : sp[j];      // tick of the last hit
+                        sn[j] = hn ? n : sn[j];
+                        ap = sp[j] > n - w;
+                        an = sn[j] > n - w;
                     }
                     const int es = (PH - D[j] + 1 - w) & (UN - 1);
                     accP[es] = ap ? 1u : accP[es];
