@@ -642,8 +642,12 @@ k_colfilter_lds(const float* __restrict__ srcW, const float* __restrict__ srcO,
     const int R2 = 2 * r;
     const size_t Cs = (size_t)C;
     const float* src = SRCMODE == 1 ? ((img == 0 ? srcW : srcO) + win * sws_img + c) : nullptr;
-    const float* sd = SRCMODE == 0 ? srcData + win * sws + c : nullptr;
+    const float* sd = SRCMODE != 1 ? srcData + win * sws + c : nullptr;
     const uint8_t* sf = SRCMODE == 0 ? srcFlags + win * sws + c : nullptr;
+    // SRCMODE 2: flags packed four line positions per 32-bit word, [n/4][C]
+    // words (byte k of word q = flag of position 4q + k): one coalesced dword
+    // load per four steps instead of a byte load per step
+    const unsigned* sf4 = SRCMODE == 2 ? reinterpret_cast<const unsigned*>(srcFlags) + win * (sws / 4) + c : nullptr;
     // TOUT: the output is written TRANSPOSED -- line c becomes row c of an
     // [C][n] image (n % 4 == 0) -- four consecutive outputs per 16-byte store,
     // so the frequency-axis stage can consume it without a transpose pass.
@@ -655,6 +659,12 @@ k_colfilter_lds(const float* __restrict__ srcW, const float* __restrict__ srcO,
     auto load = [&](int t) -> float {
         if (SRCMODE == 0) {
             bool fl = sf[(size_t)t * Cs] != 0;
+            if (img == 0) return fl ? 0.0f : 1.0f;
+            return fl ? 0.0f : sd[(size_t)t * Cs];
+        }
+        if (SRCMODE == 2) {
+            unsigned wq = sf4[(size_t)(t >> 2) * Cs];
+            bool fl = ((wq >> (8 * (t & 3))) & 0xFFu) != 0;
             if (img == 0) return fl ? 0.0f : 1.0f;
             return fl ? 0.0f : sd[(size_t)t * Cs];
         }
@@ -670,8 +680,32 @@ k_colfilter_lds(const float* __restrict__ srcW, const float* __restrict__ srcO,
     // per-thread loads, not from thread count.
     constexpr int PF = 32;
     float pre[PF], cur[PF];
+    unsigned prew[PF / 4];   // SRCMODE 2: raw packed-flag words in flight with pre[]
+    // issue the loads of samples [t0, t0 + PF); the values are only consumed one
+    // block later, so the loads stay in flight across a block of arithmetic
+    auto issue = [&](int t0) {
+        if (SRCMODE == 2) {
 #pragma unroll
-    for (int u = 0; u < PF; u++) pre[u] = (u < n) ? load(u) : 0.0f;
+            for (int q = 0; q < PF / 4; q++) {
+                int t = t0 + 4 * q;
+                prew[q] = (t < n) ? sf4[(size_t)(t >> 2) * Cs] : 0x01010101u;
+            }
+            if (img == 1) {
+#pragma unroll
+                for (int u = 0; u < PF; u++) {
+                    int t = t0 + u;
+                    pre[u] = (t < n) ? sd[(size_t)t * Cs] : 0.0f;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < PF; u++) {
+                int t = t0 + u;
+                pre[u] = (t < n) ? load(t) : 0.0f;
+            }
+        }
+    };
+    issue(0);
 
     // One cascade step.  FAST = every stage is inside its steady range
     // (4r + 3 <= m, m < n): no bounds tests, so the four float64 chains of a
@@ -751,13 +785,17 @@ k_colfilter_lds(const float* __restrict__ srcW, const float* __restrict__ srcO,
     };
 
     for (int m0 = 0; m0 < total; m0 += PF) {
+        if (SRCMODE == 2) {
 #pragma unroll
-        for (int u = 0; u < PF; u++) cur[u] = pre[u];
+            for (int u = 0; u < PF; u++) {
+                bool fl = ((prew[u >> 2] >> (8 * (u & 3))) & 0xFFu) != 0;
+                cur[u] = (img == 0) ? (fl ? 0.0f : 1.0f) : (fl ? 0.0f : pre[u]);
+            }
+        } else {
 #pragma unroll
-        for (int u = 0; u < PF; u++) {
-            int t = m0 + PF + u;
-            pre[u] = (t < n) ? load(t) : 0.0f;
+            for (int u = 0; u < PF; u++) cur[u] = pre[u];
         }
+        issue(m0 + PF);
         if (m0 >= 4 * r + 3 && m0 + PF <= n) {
 #pragma unroll
             for (int u = 0; u < PF; u++) step(std::true_type{}, m0 + u, cur[u]);
@@ -1931,6 +1969,19 @@ int launch_colfilter(const Run& r, int srcmode, float* bufW, float* bufO, const 
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_set = true;
         }
+        if (srcmode == 2) {
+            static bool attr2 = false;
+            if (!attr2) {
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<2, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr2 = true;
+            }
+            if (deferred_denom) *deferred_denom = denom;
+            else return set_err(TRI_EINVAL, "internal: packed-flag filter needs a deferred denominator");
+            hipLaunchKernelGGL((k_colfilter_lds<2, false, false>), grid, dim3(bt), lds, r.st, (const float*)nullptr, (const float*)nullptr,
+                               srcData, srcFlags, dstW, dstO, n, C, rad, denom, (size_t)0, sws, dws);
+            LAUNCHCHK();
+            return TRI_OK;
+        }
         if (transposed_out)
             hipLaunchKernelGGL((k_colfilter_lds<1, true, true>), grid, dim3(bt), lds, r.st, (const float*)bufW, (const float*)bufO,
                                srcData, srcFlags, dstW, dstO, n, C, rad, denom, bws, sws, dws);
@@ -2080,10 +2131,22 @@ int background2d(const Run& r) {
     int64_t W = r.Wb;
     size_t N = (size_t)T * Fa;
     size_t wsA = (size_t)pl.PT * Fa, wsB = (size_t)pl.PF * T;
-    int rc = launch_u8<0>(r, ws.flagsTF, ws.bgfTF, N, N, N, W);
+    // Background flags live in FT layout (ws.bgfFT).  For the time-axis stage
+    // they are needed per (time, channel) column thread: either as a TF byte
+    // image (general case) or, when T % 4 == 0, packed four times per word
+    // ("TF4": [T/4][Fa] uint32) -- which is exactly the 32-bit transpose of the
+    // FT byte image viewed as [Fa][T/4] words.
+    static const bool no_pack = [] { const char* e = getenv("TRI_NO_PACKED_FLAGS"); return e && e[0] == '1'; }();
+    const bool packed = !no_pack && (T % 4 == 0) && (N % 4 == 0);
+    int rc = launch_transpose<uint8_t>(r, ws.flagsTF, ws.bgfFT, T, Fa, N, N, W);
     if (rc) return rc;
-    rc = launch_transpose<uint8_t>(r, ws.bgfTF, ws.bgfFT, T, Fa, N, N, W);
-    if (rc) return rc;
+    if (packed) {
+        rc = launch_transpose<float>(r, reinterpret_cast<const float*>(ws.bgfFT), reinterpret_cast<float*>(ws.bgfTF), Fa, T / 4, N / 4, N / 4, W);
+        if (rc) return rc;
+    } else {
+        rc = launch_u8<0>(r, ws.flagsTF, ws.bgfTF, N, N, N, W);
+        if (rc) return rc;
+    }
     double rej = TRI_MAD_NORMAL * r.p->background_reject;
     for (int ext = pl.nit; ext >= 0; ext--) {
         bool final_pass = ext == 0;
@@ -2099,7 +2162,11 @@ int background2d(const Run& r) {
         bool direct_ft = false;
         // (for the in-place multi-pass kernel, used at large radii, building on
         //  the fly measured faster: 11.4 vs 16.8 ms per call at 128 windows)
-        if (r0 > 0 && prebuild && colfilter_lds_block(r0, Fa) > 0) {
+        if (r0 > 0 && packed && colfilter_lds_block(r0, Fa) > 0) {
+            // single sweep straight from (data, packed flags): no image build
+            rc = launch_colfilter(r, 2, ws.Aw, ws.Ao, ws.dataTF, ws.bgfTF, ws.Aw, ws.Ao, T, Fa, r0, wsA, N, wsA, W, &den_t);
+            if (rc) return rc;
+        } else if (r0 > 0 && !packed && prebuild && colfilter_lds_block(r0, Fa) > 0) {
             const bool lds_path = true;
             const size_t boff = lds_path ? 0 : (size_t)4 * r0 * Fa;
             if (N % 4 == 0 && wsA % 4 == 0)
@@ -2119,10 +2186,22 @@ int background2d(const Run& r) {
             }
             if (rc) return rc;
         } else if (r0 > 0) {
-            rc = launch_colfilter(r, 0, ws.Aw, ws.Ao, ws.dataTF, ws.bgfTF, ws.Aw, ws.Ao, T, Fa, r0, wsA, N, wsA, W);
+            const uint8_t* fl = ws.bgfTF;
+            if (packed) {   // byte image needed: rebuild it next to the packed one
+                rc = launch_transpose<uint8_t>(r, ws.bgfFT, ws.comb, Fa, T, N, N, W);
+                if (rc) return rc;
+                fl = ws.comb;
+            }
+            rc = launch_colfilter(r, 0, ws.Aw, ws.Ao, ws.dataTF, fl, ws.Aw, ws.Ao, T, Fa, r0, wsA, N, wsA, W);
             if (rc) return rc;
         } else {
-            hipLaunchKernelGGL(k_build_wo, grid1(N, W), dim3(256), 0, r.st, ws.dataTF, ws.bgfTF, ws.Aw, ws.Ao, N, N, wsA);
+            const uint8_t* fl = ws.bgfTF;
+            if (packed) {
+                rc = launch_transpose<uint8_t>(r, ws.bgfFT, ws.comb, Fa, T, N, N, W);
+                if (rc) return rc;
+                fl = ws.comb;
+            }
+            hipLaunchKernelGGL(k_build_wo, grid1(N, W), dim3(256), 0, r.st, ws.dataTF, fl, ws.Aw, ws.Ao, N, N, wsA);
             LAUNCHCHK();
         }
         // --- to FT layout: rows [4 r1, 4 r1 + Fa) of the padded buffers for the
@@ -2154,7 +2233,10 @@ int background2d(const Run& r) {
             else
                 hipLaunchKernelGGL(k_reject<true>, grid1(N, W), dim3(256), 0, r.st, ws.Bo, ws.bgfFT, ws.med, ws.d_chunk_of, rej, Fa, T, G, wsB, N);
             LAUNCHCHK();
-            rc = launch_transpose<uint8_t>(r, ws.bgfFT, ws.bgfTF, Fa, T, N, N, W);
+            if (packed)
+                rc = launch_transpose<float>(r, reinterpret_cast<const float*>(ws.bgfFT), reinterpret_cast<float*>(ws.bgfTF), Fa, T / 4, N / 4, N / 4, W);
+            else
+                rc = launch_transpose<uint8_t>(r, ws.bgfFT, ws.bgfTF, Fa, T, N, N, W);
             if (rc) return rc;
         }
     }
