@@ -358,7 +358,7 @@ k_median(const float* __restrict__ data, const uint8_t* __restrict__ flags,
 // segments per 256-thread workgroup; barriers are executed uniformly.
 // grid (ceil(R*G/4), W), block 256
 // ---------------------------------------------------------------------------
-#define MW_K 16
+#define MW_K 16   // register slots per lane of the largest instantiation (segments <= 1024)
 __device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -370,6 +370,7 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     return v;
 }
 
+template <int KS>   // register slots per lane: segments of at most 64 * KS samples
 __global__ void __launch_bounds__(256)
 k_median_wave(const float* __restrict__ data, const uint8_t* __restrict__ flags,
               double* __restrict__ med, size_t WSd, size_t WSf, size_t RS, size_t ES,
@@ -386,10 +387,10 @@ k_median_wave(const float* __restrict__ data, const uint8_t* __restrict__ flags,
     const size_t rel = (size_t)row * RS + (size_t)seg_start[g] * ES;
     const float* d = data + win * WSd + rel;
     const uint8_t* f = flags + win * WSf + rel;
-    unsigned keys[MW_K];
+    unsigned keys[KS];
     unsigned nloc = 0;
 #pragma unroll
-    for (int u = 0; u < MW_K; u++) {
+    for (int u = 0; u < KS; u++) {
         int i = u * 64 + lane;
         unsigned k = SENT;
         if (i < len) {
@@ -406,14 +407,14 @@ k_median_wave(const float* __restrict__ data, const uint8_t* __restrict__ flags,
     // the LDS atomics).
     unsigned kmin = SENT, kmax = 0;
 #pragma unroll
-    for (int u = 0; u < MW_K; u++)
+    for (int u = 0; u < KS; u++)
         if (keys[u] != SENT) { kmin = min(kmin, keys[u]); kmax = max(kmax, keys[u]); }
     kmin = ~wave_max_u32(~kmin);
     kmax = wave_max_u32(kmax);
     const int B = (n == 0 || kmax == kmin) ? 0 : 32 - __clz((int)(kmax - kmin));
     const int P = (B + 7) >> 3;
 #pragma unroll
-    for (int u = 0; u < MW_K; u++)
+    for (int u = 0; u < KS; u++)
         if (keys[u] != SENT) keys[u] -= kmin;
     unsigned prefix = 0, pmask = 0, kk = n >> 1;
     unsigned* h = hist[wave];
@@ -424,7 +425,7 @@ k_median_wave(const float* __restrict__ data, const uint8_t* __restrict__ flags,
         __syncthreads();
         if (act) {
 #pragma unroll
-            for (int u = 0; u < MW_K; u++) {
+            for (int u = 0; u < KS; u++) {
                 unsigned k = keys[u];
                 if (k != SENT && (k & pmask) == prefix) atomicAdd(&h[(k >> shift) & 0xFFu], 1u);
             }
@@ -462,7 +463,7 @@ k_median_wave(const float* __restrict__ data, const uint8_t* __restrict__ flags,
     }
     unsigned cnt = 0, mx = 0;
 #pragma unroll
-    for (int u = 0; u < MW_K; u++) {
+    for (int u = 0; u < KS; u++) {
         unsigned k = keys[u];
         if (k != SENT && k < prefix) { cnt++; mx = max(mx, k); }
     }
@@ -841,7 +842,7 @@ __global__ void k_build_wo4(const float* __restrict__ data, const uint8_t* __res
 template <int MODE>
 __global__ void k_masked_div(const float* __restrict__ w, float* __restrict__ o,
                              const float* __restrict__ data, size_t nper, size_t ws_wo,
-                             size_t ws_data, float denom) {
+                             size_t ws_data, float denom, uint8_t* __restrict__ nanflag, int C) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nper) return;
     size_t win = blockIdx.y;
@@ -849,6 +850,9 @@ __global__ void k_masked_div(const float* __restrict__ w, float* __restrict__ o,
     float ov = o[win * ws_wo + i];
     if (denom != 0.0f) { wv = wv / denom; ov = ov / denom; }   // deferred flagging.py:419
     float bg = (wv == 0.0f) ? NAN : ov / wv;
+    // remember which lines (columns) hold a NaN: only those need the
+    // sequential interpolation pass
+    if (MODE == 0 && nanflag && isnan(bg)) nanflag[win * (size_t)C + (i % C)] = 1;
     if (MODE == 1) bg = fabsf(data[win * ws_data + i] - bg);
     o[win * ws_wo + i] = bg;
 }
@@ -877,9 +881,11 @@ __global__ void k_reject(const float* __restrict__ resid, uint8_t* __restrict__ 
 // -> float64; value = f32(f32 + int64 * f64) evaluated in float64.
 // grid (ceil(C/256), W)
 // ---------------------------------------------------------------------------
-__global__ void k_colinterp(float* __restrict__ a, int L, int C, size_t ws) {
+__global__ void k_colinterp(float* __restrict__ a, int L, int C, size_t ws,
+                            const uint8_t* __restrict__ nanflag) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    if (nanflag && !nanflag[(size_t)blockIdx.y * C + c]) return;   // no NaN in this line
     float* x = a + (size_t)blockIdx.y * ws + c;
     const size_t Cs = (size_t)C;
     int last = -1;       // index of the last valid sample
@@ -1498,7 +1504,7 @@ __global__ void k_final16(const uint8_t* __restrict__ dil, const int* __restrict
 template <int MODE>
 __global__ void k_masked_div4(const float* __restrict__ w, float* __restrict__ o,
                               const float* __restrict__ data, size_t n4per, size_t ws_wo, size_t ws_data,
-                              float denom) {
+                              float denom, uint8_t* __restrict__ nanflag, int C) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4per) return;
     size_t win = blockIdx.y;
@@ -1511,6 +1517,12 @@ __global__ void k_masked_div4(const float* __restrict__ w, float* __restrict__ o
     }
     float bg[4] = {(wv.x == 0.0f) ? NAN : ov.x / wv.x, (wv.y == 0.0f) ? NAN : ov.y / wv.y,
                    (wv.z == 0.0f) ? NAN : ov.z / wv.z, (wv.w == 0.0f) ? NAN : ov.w / wv.w};
+    if (MODE == 0 && nanflag) {
+        int cb = (int)((i * 4) % C);   // C % 4 == 0: the four samples are columns cb .. cb + 3
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (isnan(bg[k])) nanflag[win * (size_t)C + cb + k] = 1;
+    }
     if (MODE == 1) {
         float4 dv = reinterpret_cast<const float4*>(data + win * ws_data)[i];
         bg[0] = fabsf(dv.x - bg[0]); bg[1] = fabsf(dv.y - bg[1]);
@@ -1914,8 +1926,11 @@ int launch_median(const Run& r, const float* data, const uint8_t* flags, double*
                   const int64_t* seg_len, int R, int G, int64_t W, int64_t max_len, bool vec_ok = false) {
     if ((int64_t)R * G <= 0 || W <= 0) return TRI_OK;
     if ((int64_t)R * G > 0x7FFFFFFF || W > 65535) return set_err(TRI_EUNSUPPORTED, "median grid too large");
-    if (max_len <= 64 * MW_K)
-        hipLaunchKernelGGL(k_median_wave, dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)W), dim3(256), 0, r.st,
+    if (max_len <= 64 * 8)
+        hipLaunchKernelGGL(k_median_wave<8>, dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)W), dim3(256), 0, r.st,
+                           data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
+    else if (max_len <= 64 * MW_K)
+        hipLaunchKernelGGL(k_median_wave<MW_K>, dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)W), dim3(256), 0, r.st,
                            data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
     else if (vec_ok)
         hipLaunchKernelGGL(k_median<true>, dim3((unsigned)(R * G), (unsigned)W), dim3(256), 0, r.st, data,
@@ -2064,11 +2079,12 @@ int launch_u8(const Run& r, const uint8_t* a, uint8_t* b, size_t nper, size_t ws
 }
 
 template <int MODE>
-int launch_masked_div(const Run& r, const float* w, float* o, const float* data, size_t nper, size_t ws_wo, size_t ws_data, int64_t W, float denom = 0.0f) {
-    if (nper % 4 == 0 && ws_wo % 4 == 0 && ws_data % 4 == 0 && ((uintptr_t)w % 16 == 0) && ((uintptr_t)o % 16 == 0))
-        hipLaunchKernelGGL(k_masked_div4<MODE>, grid1(nper / 4, W), dim3(256), 0, r.st, w, o, data, nper / 4, ws_wo, ws_data, denom);
+int launch_masked_div(const Run& r, const float* w, float* o, const float* data, size_t nper, size_t ws_wo, size_t ws_data, int64_t W, float denom = 0.0f,
+                      uint8_t* nanflag = nullptr, int C = 1) {
+    if (nper % 4 == 0 && ws_wo % 4 == 0 && ws_data % 4 == 0 && C % 4 == 0 && ((uintptr_t)w % 16 == 0) && ((uintptr_t)o % 16 == 0))
+        hipLaunchKernelGGL(k_masked_div4<MODE>, grid1(nper / 4, W), dim3(256), 0, r.st, w, o, data, nper / 4, ws_wo, ws_data, denom, nanflag, C);
     else
-        hipLaunchKernelGGL(k_masked_div<MODE>, grid1(nper, W), dim3(256), 0, r.st, w, o, data, nper, ws_wo, ws_data, denom);
+        hipLaunchKernelGGL(k_masked_div<MODE>, grid1(nper, W), dim3(256), 0, r.st, w, o, data, nper, ws_wo, ws_data, denom, nanflag, C);
     LAUNCHCHK();
     return TRI_OK;
 }
@@ -2116,7 +2132,7 @@ int spectrum_background(const Run& r) {
             LAUNCHCHK();
         }
     }
-    hipLaunchKernelGGL(k_colinterp, dim3((unsigned)cdiv(Wn, 256), 1), dim3(256), 0, r.st, ws.so, Fa, Wn, (size_t)0);
+    hipLaunchKernelGGL(k_colinterp, dim3((unsigned)cdiv(Wn, 256), 1), dim3(256), 0, r.st, ws.so, Fa, Wn, (size_t)0, (const uint8_t*)nullptr);
     LAUNCHCHK();
     return TRI_OK;
 }
@@ -2219,7 +2235,10 @@ int background2d(const Run& r) {
             if (rc) return rc;
         }
         if (final_pass) {
-            rc = launch_masked_div<0>(r, ws.Bw, ws.Bo, ws.dataFT, N, wsB, N, W, den_f);
+            // ws.rowcnt (W * T ints, idle until the end of the iteration) doubles as the
+            // per-line "background holds a NaN" marker
+            HIPCHK(hipMemsetAsync(ws.rowcnt, 0, (size_t)W * T, r.st));
+            rc = launch_masked_div<0>(r, ws.Bw, ws.Bo, ws.dataFT, N, wsB, N, W, den_f, reinterpret_cast<uint8_t*>(ws.rowcnt), T);
             if (rc) return rc;
         } else {
             rc = launch_masked_div<1>(r, ws.Bw, ws.Bo, ws.dataFT, N, wsB, N, W, den_f);
@@ -2240,7 +2259,7 @@ int background2d(const Run& r) {
             if (rc) return rc;
         }
     }
-    hipLaunchKernelGGL(k_colinterp, dim3((unsigned)cdiv(T, 256), (unsigned)W), dim3(256), 0, r.st, ws.Bo, Fa, T, wsB);
+    hipLaunchKernelGGL(k_colinterp, dim3((unsigned)cdiv(T, 256), (unsigned)W), dim3(256), 0, r.st, ws.Bo, Fa, T, wsB, reinterpret_cast<const uint8_t*>(ws.rowcnt));
     LAUNCHCHK();
     return TRI_OK;
 }
@@ -2609,8 +2628,11 @@ extern "C" int tri_test_median(const float* data, const uint8_t* flags, double* 
     if (variant == 0) variant = maxlen <= 64 * MW_K ? 1 : (al4 ? 3 : 2);
     if (variant == 1 && maxlen > 64 * MW_K) return set_err(TRI_EINVAL, "wave kernel handles segments <= 1024");
     if (variant == 3 && !al4) return set_err(TRI_EINVAL, "vector loads need 4-aligned segments");
-    if (variant == 1)
-        hipLaunchKernelGGL(k_median_wave, dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)n_win), dim3(256), 0, st,
+    if (variant == 1 && maxlen <= 64 * 8)
+        hipLaunchKernelGGL(k_median_wave<8>, dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)n_win), dim3(256), 0, st,
+                           data, flags, med, WS, WS, RS, (size_t)1, d_start, d_len, R, G);
+    else if (variant == 1)
+        hipLaunchKernelGGL(k_median_wave<MW_K>, dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)n_win), dim3(256), 0, st,
                            data, flags, med, WS, WS, RS, (size_t)1, d_start, d_len, R, G);
     else if (variant == 3)
         hipLaunchKernelGGL(k_median<true>, dim3((unsigned)(R * G), (unsigned)n_win), dim3(256), 0, st, data, flags,
