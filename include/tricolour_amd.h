@@ -152,6 +152,27 @@ int tri_unpack_data(const uint8_t *flag_windows,
                     int64_t nbl, int64_t ntime,
                     uint8_t *out_flags, void *stream);
 
+/*
+ * Replaces tricolour.flagging.flag_nans_and_zeros (flagging.py:29-62):
+ * out = (vis == 0) | isnan(vis) | (flags != 0), elementwise over n samples.
+ */
+int tri_flag_nans_and_zeros(const void *vis, int vis_dtype, const uint8_t *flags,
+                            uint8_t *out_flags, int64_t n, void *stream);
+
+/*
+ * Device half of tricolour.flagging.apply_static_mask (flagging.py:151-172,
+ * one call per mask) and flag_autos (flagging.py:90-93): out = flags, then on
+ * every baseline with bl_sel[bl] != 0 either out |= chan_mask (mode 0, "or")
+ * or out = chan_mask (mode 1, "override"), broadcast over corr and time.
+ * flags / out: (nbl, ncorr, ntime, nchan) uint8; may alias.  The channel mask
+ * and the baseline selection (uv-range test on antenna positions) are
+ * computed on the host exactly as flagging.py:131-160 does.
+ */
+int tri_apply_baseline_channel_mask(const uint8_t *flags, uint8_t *out_flags,
+                                    const uint8_t *bl_sel, const uint8_t *chan_mask,
+                                    int mode, int64_t nbl, int64_t ncorr, int64_t ntime,
+                                    int64_t nchan, void *stream);
+
 /* Thread-local description of the last failure in the calling thread. */
 const char *tri_last_error(void);
 

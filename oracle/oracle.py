@@ -348,3 +348,44 @@ def unpack_data(time_inv, ubl, ant1, ant2, flag_windows):
                           _p(np.ascontiguousarray(flag_windows != 0).view(np.uint8)),
                           _p(out))
     return out.view(np.bool_)
+
+
+# ---- cheap strategy steps (numpy restatements) ------------
+
+def flag_nans_and_zeros(vis_windows, flag_windows):
+    """flagging.py:29-62."""
+    if vis_windows.shape != flag_windows.shape:
+        raise ValueError("vis_windows.shape != flag_windows.shape")
+    flag = (vis_windows == 0) | np.isnan(vis_windows) | (flag_windows != 0)
+    return flag.astype(flag_windows.dtype)
+
+
+def flag_autos(flags, ubl):
+    """flagging.py:65-95 (ubl wrapped in a list, :84)."""
+    ubl = ubl[0]
+    if flags.shape[0] != ubl.shape[0]:
+        raise ValueError("flag and ubl shape mismatch")
+    out = flags.copy()
+    out[ubl[:, 1] == ubl[:, 2], :, :, :] = True
+    return out
+
+
+def apply_static_mask(flag, ubl, antspos, masks, chan_freqs, chan_widths,
+                      accumulation_mode="or", uvrange=(0, np.inf)):
+    """flagging.py:98-172 with the uv-range already parsed to (lo, hi)."""
+    spw_chanlb = chan_freqs - chan_widths * 0.5
+    spw_chanub = chan_freqs + chan_widths * 0.5
+    bl_length = antspos[ubl[:, 1]] - antspos[ubl[:, 2]]
+    d2 = 0.5 * np.sum(bl_length**2, axis=1)
+    lo, hi = min(uvrange), max(uvrange)
+    bl_sel = np.logical_and(d2 >= lo**2, d2 <= hi**2)
+    out = flag.copy()
+    for mask in masks:
+        mc = np.logical_and(mask >= spw_chanlb[None, :], mask < spw_chanub[None, :]).sum(axis=0) > 0
+        if accumulation_mode == "or":
+            out[bl_sel, :, :, :] |= mc[None, None, None, :].astype(out.dtype)
+        elif accumulation_mode == "override":
+            out[bl_sel, :, :, :] = mc[None, None, None, :]
+        else:
+            raise ValueError("Invalid accumulation_mode")
+    return out

@@ -2646,3 +2646,73 @@ extern "C" int tri_test_median(const float* data, const uint8_t* flags, double* 
     (void)hipFree(d_len);
     return TRI_OK;
 }
+
+// ===========================================================================
+// "Next" rows: the cheap strategy steps that surround
+// sum_threshold in conf/default.yaml, so a whole strategy chain can stay
+// device-resident.
+// ===========================================================================
+// flag_nans_and_zeros (flagging.py:29-62): out = vis == 0 | isnan(vis) | flags != 0
+template <int VD>
+__global__ void k_flag_nans_zeros(const void* __restrict__ vis, const uint8_t* __restrict__ flags,
+                                  uint8_t* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool f;
+    if (VD == TRI_VIS_C64) {
+        float2 z = reinterpret_cast<const float2*>(vis)[i];
+        f = (z.x == 0.0f && z.y == 0.0f) || isnan(z.x) || isnan(z.y);
+    } else {
+        float x = reinterpret_cast<const float*>(vis)[i];
+        f = x == 0.0f || isnan(x);
+    }
+    out[i] = (f || flags[i] != 0) ? 1 : 0;
+}
+
+// out = flags, then for every selected baseline: out |= chan_mask (mode 0) or
+// out = chan_mask (mode 1), broadcast over corr and time.  Serves
+// apply_static_mask (flagging.py:151-172, one call per mask) and flag_autos
+// (flagging.py:90-93: all-ones mask on the auto-correlation baselines).
+// In-place safe (out == flags).  grid (ceil(nchan/256), ncorr*ntime, nbl)
+__global__ void k_apply_bl_chan_mask(const uint8_t* __restrict__ flags, uint8_t* __restrict__ out,
+                                     const uint8_t* __restrict__ bl_sel,
+                                     const uint8_t* __restrict__ chan_mask, int mode, int nchan,
+                                     size_t rows_per_bl) {
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nchan) return;
+    size_t bl = blockIdx.z;
+    size_t a = (bl * rows_per_bl + blockIdx.y) * (size_t)nchan + f;
+    uint8_t v = flags[a];
+    if (bl_sel[bl]) v = mode == 0 ? (uint8_t)((v | chan_mask[f]) ? 1 : 0) : (uint8_t)(chan_mask[f] ? 1 : 0);
+    out[a] = v;
+}
+
+extern "C" int tri_flag_nans_and_zeros(const void* vis, int vis_dtype, const uint8_t* flags,
+                                       uint8_t* out_flags, int64_t n, void* stream) {
+    if (!vis || !flags || !out_flags || n < 0) return set_err(TRI_EINVAL, "bad argument");
+    if (vis_dtype != TRI_VIS_C64 && vis_dtype != TRI_VIS_F32) return set_err(TRI_EUNSUPPORTED, "vis dtype must be complex64 or float32");
+    if (n == 0) return TRI_OK;
+    dim3 grid((unsigned)cdiv(n, 256));
+    if (vis_dtype == TRI_VIS_C64)
+        hipLaunchKernelGGL(k_flag_nans_zeros<TRI_VIS_C64>, grid, dim3(256), 0, (hipStream_t)stream, vis, flags, out_flags, (size_t)n);
+    else
+        hipLaunchKernelGGL(k_flag_nans_zeros<TRI_VIS_F32>, grid, dim3(256), 0, (hipStream_t)stream, vis, flags, out_flags, (size_t)n);
+    LAUNCHCHK();
+    return TRI_OK;
+}
+
+extern "C" int tri_apply_baseline_channel_mask(const uint8_t* flags, uint8_t* out_flags,
+                                               const uint8_t* bl_sel, const uint8_t* chan_mask,
+                                               int mode, int64_t nbl, int64_t ncorr, int64_t ntime,
+                                               int64_t nchan, void* stream) {
+    if (!flags || !out_flags || !bl_sel || !chan_mask) return set_err(TRI_EINVAL, "NULL pointer argument");
+    if (mode != 0 && mode != 1) return set_err(TRI_EINVAL, "mode must be 0 (or) or 1 (override)");
+    if (nbl < 0 || ncorr < 0 || ntime < 0 || nchan < 0) return set_err(TRI_EINVAL, "bad shape");
+    if (nbl == 0 || ncorr * ntime == 0 || nchan == 0) return TRI_OK;
+    if (ncorr * ntime > 65535 || nbl > 65535) return set_err(TRI_EUNSUPPORTED, "corr*time and bl must each be <= 65535 per call");
+    dim3 grid((unsigned)cdiv(nchan, 256), (unsigned)(ncorr * ntime), (unsigned)nbl);
+    hipLaunchKernelGGL(k_apply_bl_chan_mask, grid, dim3(256), 0, (hipStream_t)stream, flags, out_flags, bl_sel,
+                       chan_mask, mode, (int)nchan, (size_t)(ncorr * ntime));
+    LAUNCHCHK();
+    return TRI_OK;
+}

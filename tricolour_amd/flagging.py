@@ -237,3 +237,120 @@ def sum_threshold_flagger(vis, flags, outlier_nsigma=4.5,
     if from_numpy:
         return out.cpu().numpy()
     return out
+
+
+# ---------------------------------------------------------------------------
+# The cheap strategy steps around sum_threshold, same
+# signatures as the reference so a default.yaml chain can stay on the device.
+# ---------------------------------------------------------------------------
+def _flags_u8(torch, f, device):
+    if isinstance(f, np.ndarray):
+        f = torch.from_numpy(np.ascontiguousarray(f))
+    f = f.to(device)
+    if f.dtype in (torch.bool, torch.uint8, torch.int8):
+        return f.contiguous().view(torch.uint8)
+    return (f != 0).view(torch.uint8)
+
+
+def flag_nans_and_zeros(vis_windows, flag_windows):
+    """Flag nan and zero visibilities -- ``tricolour.flagging.flag_nans_and_zeros``
+    (flagging.py:29-62): ``(vis == 0) | isnan(vis) | (flags != 0)``; output has
+    the dtype of ``flag_windows`` (np.zeros_like, flagging.py:51)."""
+    if tuple(vis_windows.shape) != tuple(flag_windows.shape):
+        raise ValueError("vis_windows.shape != flag_windows.shape")   # flagging.py:46-47
+    torch = _require_gpu()
+    v, f8, code, from_numpy, device = _as_device_inputs(torch, vis_windows, flag_windows)
+    if code == -64:
+        raise TypeError("tricolour_amd.flag_nans_and_zeros: visibilities must be complex64 or float32")
+    f8 = _flags_u8(torch, flag_windows, device)
+    out = torch.empty(f8.shape, dtype=torch.uint8, device=device)
+    with torch.cuda.device(device):
+        _lib.check(_lib.lib().tri_flag_nans_and_zeros(
+            v.data_ptr(), code, f8.data_ptr(), out.data_ptr(), out.numel(),
+            torch.cuda.current_stream(device).cuda_stream))
+    return _like_flags(torch, out, flag_windows, from_numpy)
+
+
+def _like_flags(torch, out_u8, like, from_numpy):
+    """uint8 0/1 result -> the container / dtype of the reference's output."""
+    if from_numpy:
+        o = out_u8.cpu().numpy()
+        dt = like.dtype if isinstance(like, np.ndarray) else np.bool_
+        return o.view(np.bool_) if dt == np.bool_ else o.astype(dt)
+    if torch.is_tensor(like) and like.dtype != torch.bool:
+        return out_u8.to(like.dtype)
+    return out_u8.view(torch.bool)
+
+
+def _apply_bl_chan(torch, flags, bl_sel, chan_masks, mode):
+    from_numpy = isinstance(flags, np.ndarray)
+    device = flags.device if (torch.is_tensor(flags) and flags.is_cuda) else \
+        torch.device("cuda", torch.cuda.current_device())
+    f8 = _flags_u8(torch, flags, device)
+    nbl, ncorr, ntime, nchan = (int(x) for x in f8.shape)
+    out = f8.clone()                                   # flagging.py:90, 151: flags.copy()
+    sel = torch.from_numpy(np.ascontiguousarray(bl_sel, np.uint8)).to(device)
+    lib = _lib.lib()
+    with torch.cuda.device(device):
+        stream = torch.cuda.current_stream(device).cuda_stream
+        for cm in chan_masks:
+            m = torch.from_numpy(np.ascontiguousarray(cm, np.uint8)).to(device)
+            _lib.check(lib.tri_apply_baseline_channel_mask(
+                out.data_ptr(), out.data_ptr(), sel.data_ptr(), m.data_ptr(), mode,
+                nbl, ncorr, ntime, nchan, stream))
+    return _like_flags(torch, out, flags, from_numpy)
+
+
+def flag_autos(flags, ubl):
+    """Flags auto-correlations -- ``tricolour.flagging.flag_autos``
+    (flagging.py:65-95).  ``ubl`` arrives wrapped in a list, as dask's
+    ``bl-comp`` contraction delivers it (flagging.py:84)."""
+    ubl = np.asarray(ubl[0])
+    if flags.shape[0] != ubl.shape[0]:
+        raise ValueError("flag and ubl shape mismatch %s != %s" % (flags.shape[2], ubl.shape[0]))
+    torch = _require_gpu()
+    bl_sel = ubl[:, 1] == ubl[:, 2]
+    return _apply_bl_chan(torch, flags, bl_sel, [np.ones(int(flags.shape[3]), np.uint8)], 0)
+
+
+def static_mask_selection(ubl, antspos, masks, chan_freqs, chan_widths, uvrange=""):
+    """Host half of ``apply_static_mask`` (flagging.py:131-160): the baseline
+    selection from the uv-range and one boolean channel mask per static mask."""
+    from tricolour_amd.util import casa_style_range
+    uvrange = casa_style_range(uvrange)
+    ubl = np.asarray(ubl)
+    antspos = np.asarray(antspos)
+    spw_chanlb = chan_freqs - chan_widths * 0.5
+    spw_chanub = chan_freqs + chan_widths * 0.5
+    bl_length = antspos[ubl[:, 1]] - antspos[ubl[:, 2]]
+    d2 = 0.5 * np.sum(bl_length**2, axis=1)
+    luvrange = 0.0 if uvrange is None else min(uvrange[0], uvrange[1])
+    uuvrange = np.inf if uvrange is None else max(uvrange[0], uvrange[1])
+    bl_sel = np.logical_and(d2 >= luvrange**2, d2 <= uuvrange**2)
+    chan_masks = []
+    for mask in masks:
+        mask = np.asarray(mask)
+        if mask.ndim != 2 and mask.shape[1] != 1:
+            raise ValueError("masks.shape != (dim, 1)")
+        lower_mask = mask[:, :] >= spw_chanlb[None, :]
+        upper_mask = mask[:, :] < spw_chanub[None, :]
+        chan_masks.append(np.logical_and(lower_mask, upper_mask).sum(axis=0) > 0)
+    return bl_sel, chan_masks
+
+
+def apply_static_mask(flag, ubl, antspos, masks, chan_freqs, chan_widths,
+                      accumulation_mode="or", uvrange=""):
+    """Applies static masks -- ``tricolour.flagging.apply_static_mask``
+    (flagging.py:98-172): channels whose band contains a masked frequency are
+    flagged ("or") or replace the flags ("override") on the baselines inside
+    ``uvrange``."""
+    ubl = np.asarray(ubl)
+    if flag.shape[0] != ubl.shape[0]:
+        raise ValueError("flag and ubl shape mismatch %s != %s" % (flag.shape[1], ubl.shape[0]))
+    if accumulation_mode not in ("or", "override"):
+        if len(masks) > 0:
+            raise ValueError("Invalid accumulation_mode '%s'. Should be 'or' or 'override'"
+                             % accumulation_mode)
+    bl_sel, chan_masks = static_mask_selection(ubl, antspos, masks, chan_freqs, chan_widths, uvrange)
+    torch = _require_gpu()
+    return _apply_bl_chan(torch, flag, bl_sel, chan_masks, 0 if accumulation_mode == "or" else 1)
