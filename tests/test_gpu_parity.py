@@ -206,3 +206,105 @@ def test_median_kernels(gpu, rows, row_len, ends, variants):
         got = med.cpu().numpy()
         same = (got == exp) | (np.isnan(got) & np.isnan(exp))
         assert same.all(), "variant %d: %d medians differ" % (variant, (~same).sum())
+
+
+EDGE_CASES = [
+    # (shape, kwargs)
+    ((1, 1, 1, 16), dict(num_major_iterations=1)),
+    ((1, 1, 16, 1), dict(num_major_iterations=1, freq_chunks=1)),
+    ((2, 1, 3, 5), dict(num_major_iterations=2, freq_chunks=7)),          # more chunks than channels
+    ((1, 2, 20, 33), dict(num_major_iterations=1, background_iterations=0)),
+    ((1, 1, 24, 48), dict(num_major_iterations=1, time_extend=0, freq_extend=0)),
+    ((1, 1, 24, 48), dict(num_major_iterations=2, time_extend=4, freq_extend=6)),
+    ((1, 1, 24, 48), dict(num_major_iterations=1, time_extend=1, freq_extend=33)),
+    ((1, 1, 30, 64), dict(num_major_iterations=1, windows_time=[8, 1, 4], windows_freq=[3, 5.5, 7])),
+    ((1, 1, 12, 40), dict(num_major_iterations=1, windows_time=[1, 2, 4, 8, 16, 64], windows_freq=[1, 64])),
+    ((1, 1, 40, 64), dict(num_major_iterations=1, flag_all_time_frac=0.0, flag_all_freq_frac=0.0)),
+    ((1, 1, 40, 64), dict(num_major_iterations=1, flag_all_time_frac=1.0, flag_all_freq_frac=1.0)),
+    ((1, 1, 40, 64), dict(num_major_iterations=1, spike_width_time=0.1, spike_width_freq=0.1)),   # r = 0 on both axes
+    ((1, 1, 40, 64), dict(num_major_iterations=1, spike_width_time=0.1, spike_width_freq=6.0)),
+    ((1, 1, 40, 64), dict(num_major_iterations=1, spike_width_time=6.0, spike_width_freq=0.1)),
+    ((1, 1, 36, 60), dict(num_major_iterations=2, average_freq=3, windows_freq=[3, 6, 12], freq_chunks=2)),
+    ((1, 1, 64, 128), dict(num_major_iterations=1, outlier_nsigma=0.0)),
+    ((3, 1, 16, 32), dict(num_major_iterations=0)),
+    ((1, 1, 128, 64), dict(num_major_iterations=1, spike_width_time=45.0, background_iterations=2)),  # radii up to 77
+]
+
+
+@pytest.mark.parametrize("case", range(len(EDGE_CASES)))
+def test_edge_cases_vs_oracle(gpu, oracle, case):
+    shape, kw = EDGE_CASES[case]
+    rs = np.random.RandomState(1000 + case)
+    vis = (rs.standard_normal(shape) + 1j * rs.standard_normal(shape)).astype(np.complex64)
+    if shape[3] > 4:
+        vis[..., shape[3] // 3] *= 7
+    if shape[2] > 4:
+        vis[:, :, shape[2] // 2, :] *= 5
+    flags = rs.uniform(size=shape) < 0.05
+    out = gpu.sum_threshold_flagger(vis, flags, **kw)
+    if kw.get("num_major_iterations", 5) == 0:
+        assert out.shape == shape and out.dtype == np.bool_   # reference: np.empty_like
+        return
+    exp = oracle.sum_threshold_flagger(vis, flags, **kw)
+    assert np.array_equal(out, exp), "%d of %d flags differ" % ((out != exp).sum(), out.size)
+
+
+def test_empty_inputs(gpu):
+    for shape in ((0, 4, 8, 16), (2, 0, 8, 16)):
+        out = gpu.sum_threshold_flagger(np.zeros(shape, np.complex64), np.zeros(shape, bool))
+        assert out.shape == shape and out.dtype == np.bool_
+
+
+def test_full_size_window_vs_oracle(gpu, oracle):
+    """One MeerKAT-sized (1024 x 4096) window pair, bit-exact against the
+    oracle (the oracle needs a few seconds per window and iteration)."""
+    import torch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(99)
+    shape = (1, 2, 1024, 4096)
+    re = torch.randn(shape, generator=g, device="cuda")
+    im = torch.randn(shape, generator=g, device="cuda")
+    re[..., ::97] += 8.0
+    re[:, :, ::211, :] += 6.0
+    re[0, 0, 100:140, 2000:2300] += 2.0
+    re.view(-1)[torch.randint(0, re.numel(), (500,), generator=g, device="cuda")] += 50.0
+    re.view(-1)[torch.randint(0, re.numel(), (50,), generator=g, device="cuda")] = float("nan")
+    vis = torch.complex(re, im)
+    flags = torch.zeros(shape, dtype=torch.bool, device="cuda")
+    flags[..., ::50] = True
+    flags[0, 1, 300:320, :] = True
+    kw = dict(num_major_iterations=2)
+    out = gpu.sum_threshold_flagger(vis, flags, **kw).cpu().numpy()
+    exp = oracle.sum_threshold_flagger(vis.cpu().numpy(), flags.cpu().numpy(), n_threads=2, **kw)
+    nbad = int((out != exp).sum())
+    assert nbad == 0, "%d of %d flags differ" % (nbad, out.size)
+
+
+def test_size_independent_properties_at_slab_scale(gpu):
+    """Properties that need no oracle, on a multi-GB slab: determinism,
+    independence of a window's result from its batch neighbours, all-flagged
+    input -> no output flags (tests/test_flagging.py:619-630 of the reference),
+    NaN samples always flagged."""
+    import torch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    shape = (12, 4, 1024, 4096)
+    vis = torch.complex(torch.randn(shape, generator=g, device="cuda"),
+                        torch.randn(shape, generator=g, device="cuda"))
+    vis.real[..., 1000] += 9.0
+    vis.real[3, 1, 17, :] += 7.0
+    nan_idx = torch.randint(0, vis.numel(), (200,), generator=g, device="cuda")
+    torch.view_as_real(vis).view(-1, 2)[nan_idx, 0] = float("nan")
+    flags = torch.zeros(shape, dtype=torch.bool, device="cuda")
+    flags[..., ::64] = True
+    flags[5] = True                                   # a fully flagged baseline
+    kw = dict(num_major_iterations=2)
+    a = gpu.sum_threshold_flagger(vis, flags, **kw)
+    b = gpu.sum_threshold_flagger(vis, flags, **kw)
+    assert torch.equal(a, b)
+    sub = gpu.sum_threshold_flagger(vis[7:9].contiguous(), flags[7:9].contiguous(), **kw)
+    assert torch.equal(sub, a[7:9])
+    nanmask = torch.isnan(vis.real) | torch.isnan(vis.imag)
+    assert bool(a[nanmask].all())
+    allflag = a[5] & ~nanmask[5]
+    assert not bool(allflag.any())

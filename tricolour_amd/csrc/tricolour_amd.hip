@@ -1130,7 +1130,11 @@ k_colst_fused(const float* __restrict__ data, const double* __restrict__ med,
         thr[j] = (double)thr0 / fa.tf[j];
         T[j] = thr[j] * (double)W[j];
         float l = (float)thr[j];
-        if ((double)l > thr[j]) l = __uint_as_float(__float_as_uint(l) - 1u);   // thr > 0 here
+        if ((double)l > thr[j]) {   // rounded up: step to the next float32 below
+            unsigned b = __float_as_uint(l);
+            b = (l > 0.0f) ? b - 1u : ((l < 0.0f) ? b + 1u : 0x80000001u);
+            l = __uint_as_float(b);
+        }
         lim[j] = l;
     }
     double cumlast[4] = {0.0, 0.0, 0.0, 0.0};
