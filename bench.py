@@ -174,6 +174,11 @@ def main():
     ap.add_argument("--time", type=int, default=1024)
     ap.add_argument("--chan", type=int, default=4096)
     ap.add_argument("--params", choices=sorted(PARAM_SETS), default="defaults")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
+                         "several ranks on one GPU)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal: map every rank to cuda:0 (with --backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -189,8 +194,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dev_index = 0 if args.share_gpu else local_rank
+        torch.cuda.set_device(dev_index)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
     else:
         torch.cuda.set_device(0)
     device = torch.device("cuda", torch.cuda.current_device())
@@ -218,7 +227,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        tt = torch.tensor([dt], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     flagged = float(out.float().mean().item()) if out is not None else float("nan")
