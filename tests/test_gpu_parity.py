@@ -169,6 +169,8 @@ def _np_median_abs(vals):
 
 @pytest.mark.parametrize("rows,row_len,ends,variants", [
     (5, 1024, [0, 1024], (1, 2, 3)),
+    (3, 1000, [0, 1000], (1, 2, 3)),
+    (2, 772, [0, 772], (1,)),
     (3, 410, [0, 41, 82, 123, 410], (1, 2)),
     (2, 4096, [0, 4, 8, 2048, 4096], (2, 3)),
     (1, 6000, [0, 1, 2, 3001, 6000], (2,)),

@@ -370,7 +370,7 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     return v;
 }
 
-template <int KS>   // register slots per lane: segments of at most 64 * KS samples
+template <int KS, bool VEC4>   // KS register slots per lane: segments of at most 64 * KS samples
 __global__ void __launch_bounds__(256)
 k_median_wave(const float* __restrict__ data, const uint8_t* __restrict__ flags,
               double* __restrict__ med, size_t WSd, size_t WSf, size_t RS, size_t ES,
@@ -389,15 +389,41 @@ k_median_wave(const float* __restrict__ data, const uint8_t* __restrict__ flags,
     const uint8_t* f = flags + win * WSf + rel;
     unsigned keys[KS];
     unsigned nloc = 0;
+    if (VEC4) {
+        // contiguous, 16-byte aligned segment: float4 / uchar4 loads (a selection
+        // does not care which lane holds which sample)
 #pragma unroll
-    for (int u = 0; u < KS; u++) {
-        int i = u * 64 + lane;
-        unsigned k = SENT;
-        if (i < len) {
-            size_t a = (size_t)i * ES;
-            if (!f[a]) { k = __float_as_uint(d[a]) & 0x7FFFFFFFu; nloc++; }
+        for (int u4 = 0; u4 < KS / 4; u4++) {
+            int i = (u4 * 64 + lane) * 4;
+            float4 dv = make_float4(0.f, 0.f, 0.f, 0.f);
+            uchar4 fv = make_uchar4(1, 1, 1, 1);
+            if (i + 3 < len) {
+                dv = *reinterpret_cast<const float4*>(d + i);
+                fv = *reinterpret_cast<const uchar4*>(f + i);
+            } else if (i < len) {
+                float dd[4] = {0.f, 0.f, 0.f, 0.f};
+                unsigned char ff[4] = {1, 1, 1, 1};
+                for (int q = 0; q < 4 && i + q < len; q++) { dd[q] = d[i + q]; ff[q] = f[i + q]; }
+                dv = make_float4(dd[0], dd[1], dd[2], dd[3]);
+                fv = make_uchar4(ff[0], ff[1], ff[2], ff[3]);
+            }
+            keys[4 * u4 + 0] = fv.x ? SENT : (__float_as_uint(dv.x) & 0x7FFFFFFFu);
+            keys[4 * u4 + 1] = fv.y ? SENT : (__float_as_uint(dv.y) & 0x7FFFFFFFu);
+            keys[4 * u4 + 2] = fv.z ? SENT : (__float_as_uint(dv.z) & 0x7FFFFFFFu);
+            keys[4 * u4 + 3] = fv.w ? SENT : (__float_as_uint(dv.w) & 0x7FFFFFFFu);
+            nloc += (fv.x ? 0 : 1) + (fv.y ? 0 : 1) + (fv.z ? 0 : 1) + (fv.w ? 0 : 1);
         }
-        keys[u] = k;
+    } else {
+#pragma unroll
+        for (int u = 0; u < KS; u++) {
+            int i = u * 64 + lane;
+            unsigned k = SENT;
+            if (i < len) {
+                size_t a = (size_t)i * ES;
+                if (!f[a]) { k = __float_as_uint(d[a]) & 0x7FFFFFFFu; nloc++; }
+            }
+            keys[u] = k;
+        }
     }
     const unsigned n = wave_sum_u32(nloc);
     // Normalise the keys to their minimum and radix-select only the B
@@ -1927,14 +1953,21 @@ bool st_use_fused(const StWin& sw) {
 
 int launch_median(const Run& r, const float* data, const uint8_t* flags, double* med, size_t WSd,
                   size_t WSf, size_t RS, size_t ES, const int64_t* seg_start,
-                  const int64_t* seg_len, int R, int G, int64_t W, int64_t max_len, bool vec_ok = false) {
+                  const int64_t* seg_len, int R, int G, int64_t W, int64_t max_len, bool vec_ok = false,
+                  bool whole_rows = false) {
     if ((int64_t)R * G <= 0 || W <= 0) return TRI_OK;
     if ((int64_t)R * G > 0x7FFFFFFF || W > 65535) return set_err(TRI_EUNSUPPORTED, "median grid too large");
+    // whole-row segments of 4-aligned rows can be loaded 16 bytes at a time
+    const bool row4 = G == 1 && ES == 1 && RS % 4 == 0 && WSd % 4 == 0 && WSf % 4 == 0 && max_len % 4 == 0 &&
+                      ((uintptr_t)data % 16 == 0) && ((uintptr_t)flags % 4 == 0) && whole_rows;
     if (max_len <= 64 * 8)
-        hipLaunchKernelGGL(k_median_wave<8>, dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)W), dim3(256), 0, r.st,
+        hipLaunchKernelGGL((k_median_wave<8, false>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)W), dim3(256), 0, r.st,
+                           data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
+    else if (max_len <= 64 * MW_K && row4)
+        hipLaunchKernelGGL((k_median_wave<MW_K, true>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)W), dim3(256), 0, r.st,
                            data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
     else if (max_len <= 64 * MW_K)
-        hipLaunchKernelGGL(k_median_wave<MW_K>, dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)W), dim3(256), 0, r.st,
+        hipLaunchKernelGGL((k_median_wave<MW_K, false>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)W), dim3(256), 0, r.st,
                            data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
     else if (vec_ok)
         hipLaunchKernelGGL(k_median<true>, dim3((unsigned)(R * G), (unsigned)W), dim3(256), 0, r.st, data,
@@ -2085,7 +2118,7 @@ int launch_u8(const Run& r, const uint8_t* a, uint8_t* b, size_t nper, size_t ws
 template <int MODE>
 int launch_masked_div(const Run& r, const float* w, float* o, const float* data, size_t nper, size_t ws_wo, size_t ws_data, int64_t W, float denom = 0.0f,
                       uint8_t* nanflag = nullptr, int C = 1) {
-    if (nper % 4 == 0 && ws_wo % 4 == 0 && ws_data % 4 == 0 && C % 4 == 0 && ((uintptr_t)w % 16 == 0) && ((uintptr_t)o % 16 == 0))
+    if (nper % 4 == 0 && ws_wo % 4 == 0 && ws_data % 4 == 0 && (nanflag == nullptr || C % 4 == 0) && ((uintptr_t)w % 16 == 0) && ((uintptr_t)o % 16 == 0))
         hipLaunchKernelGGL(k_masked_div4<MODE>, grid1(nper / 4, W), dim3(256), 0, r.st, w, o, data, nper / 4, ws_wo, ws_data, denom, nanflag, C);
     else
         hipLaunchKernelGGL(k_masked_div<MODE>, grid1(nper, W), dim3(256), 0, r.st, w, o, data, nper, ws_wo, ws_data, denom, nanflag, C);
@@ -2293,7 +2326,7 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
     if (rc) return rc;
 
     // flagging.py:944  _time_median: rows of the FT layout are contiguous in time
-    rc = launch_median(r, ws.dataFT, ws.flagsFT, ws.med, N, N, (size_t)T, 1, ws.segT_start, ws.segT_len, Fa, 1, W, pl.T);
+    rc = launch_median(r, ws.dataFT, ws.flagsFT, ws.med, N, N, (size_t)T, 1, ws.segT_start, ws.segT_len, Fa, 1, W, pl.T, false, true);
     if (rc) return rc;
     hipLaunchKernelGGL(k_spec_from_med, dim3((unsigned)cdiv((size_t)Fa * Wn, 256)), dim3(256), 0, r.st, ws.med, ws.sdata, ws.sflags, Fa, Wn);
     LAUNCHCHK();
@@ -2335,7 +2368,7 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
     // contiguous rows of the FT layout; flags = input | spectral flags.
     rc = launch_transpose<uint8_t>(r, ws.flagsTF, ws.flagsFT, T, Fa, N, N, W);
     if (rc) return rc;
-    rc = launch_median(r, residFT, ws.flagsFT, ws.med, wsB, N, (size_t)T, 1, ws.segT_start, ws.segT_len, Fa, 1, W, pl.T);
+    rc = launch_median(r, residFT, ws.flagsFT, ws.med, wsB, N, (size_t)T, 1, ws.segT_start, ws.segT_len, Fa, 1, W, pl.T, false, true);
     if (rc) return rc;
     rc = launch_colst(r, pl.swT, residTF, ws.med, ws.tflTF, ws.d_tends, T, Fa, 1, N, N, W);
     if (rc) return rc;
@@ -2633,10 +2666,13 @@ extern "C" int tri_test_median(const float* data, const uint8_t* flags, double* 
     if (variant == 1 && maxlen > 64 * MW_K) return set_err(TRI_EINVAL, "wave kernel handles segments <= 1024");
     if (variant == 3 && !al4) return set_err(TRI_EINVAL, "vector loads need 4-aligned segments");
     if (variant == 1 && maxlen <= 64 * 8)
-        hipLaunchKernelGGL(k_median_wave<8>, dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)n_win), dim3(256), 0, st,
+        hipLaunchKernelGGL((k_median_wave<8, false>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)n_win), dim3(256), 0, st,
+                           data, flags, med, WS, WS, RS, (size_t)1, d_start, d_len, R, G);
+    else if (variant == 1 && G == 1 && al4 && seg_ends[0] == 0 && seg_ends[1] == row_len)
+        hipLaunchKernelGGL((k_median_wave<MW_K, true>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)n_win), dim3(256), 0, st,
                            data, flags, med, WS, WS, RS, (size_t)1, d_start, d_len, R, G);
     else if (variant == 1)
-        hipLaunchKernelGGL(k_median_wave<MW_K>, dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)n_win), dim3(256), 0, st,
+        hipLaunchKernelGGL((k_median_wave<MW_K, false>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)n_win), dim3(256), 0, st,
                            data, flags, med, WS, WS, RS, (size_t)1, d_start, d_len, R, G);
     else if (variant == 3)
         hipLaunchKernelGGL(k_median<true>, dim3((unsigned)(R * G), (unsigned)n_win), dim3(256), 0, st, data, flags,
