@@ -833,6 +833,122 @@ k_colfilter_lds(const float* __restrict__ srcW, const float* __restrict__ srcO,
     }
 }
 
+// ---------------------------------------------------------------------------
+// K4c  "Lane-per-stage" form of the single-sweep box filter for medium radii
+// (the four 2r-deep delay lines of K4b no longer fit LDS at useful occupancy):
+// the four cascade stages of one line run in the four lanes of a quad, every
+// thread owning ONE stage and ONE LDS ring (2r floats), so the same LDS holds
+// four times the threads.  Stage p takes its input from lane p-1's output of
+// the previous step (DPP quad shuffle); the quad's four lanes prefetch four
+// consecutive line positions per load instruction and the stage-0 lane picks
+// them up by DPP broadcast.  Arithmetic per stage is identical to K4b (same
+// causal running sums, same order) -- only the thread that executes a stage
+// differs.  One wave (16 lines) per workgroup; no barriers.
+// grid (ceil(C/16), W, 2 images), block 64, dynamic LDS 2r * 64 floats
+// ---------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+// quad_perm(a,b,c,d): lane i of each quad reads lane {a,b,c,d}[i]
+#define QUAD_PERM(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
+
+template <int SRCMODE, bool DIV>
+__global__ void __launch_bounds__(64)
+k_colfilter_lane4(const float* __restrict__ srcW, const float* __restrict__ srcO,
+                  const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags,
+                  float* __restrict__ dstW, float* __restrict__ dstO,
+                  int n, int C, int r, float denom, size_t sws_img, size_t sws, size_t dws) {
+    extern __shared__ float cf_ring[];
+    const int lane = threadIdx.x;
+    const int p = lane & 3;                         // cascade stage of this lane
+    const int c = blockIdx.x * 16 + (lane >> 2);
+    const bool colok = c < C;
+    const int cc = colok ? c : C - 1;               // out-of-range quads compute on a valid column, store nothing
+    const size_t win = blockIdx.y;
+    const int img = blockIdx.z;
+    const int R2 = 2 * r;
+    const size_t Cs = (size_t)C;
+    const float* src = SRCMODE == 1 ? ((img == 0 ? srcW : srcO) + win * sws_img + cc) : nullptr;
+    const float* sd = SRCMODE != 1 ? srcData + win * sws + cc : nullptr;
+    const unsigned* sf4 = SRCMODE == 2 ? reinterpret_cast<const unsigned*>(srcFlags) + win * (sws / 4) + cc : nullptr;
+    float* dst = (img == 0 ? dstW : dstO) + win * dws + cc;
+    float* ring = cf_ring + lane;                   // slot k at ring[k * 64]
+    for (int k = 0; k < R2; k++) ring[k * 64] = 0.0f;
+
+    // per-stage ranges (see K4b): stage p runs for t in [0, tend); its input is
+    // the upstream value for t in [ilo, ihi), zero otherwise
+    const int tend = (p == 0) ? n + R2 : n + 4 * r;
+    const int ilo = (p == 3) ? R2 : 0;
+    const int ihi = (p == 0) ? n : ((p == 1) ? n + R2 : n + 4 * r);
+
+    constexpr int PF = 32;                          // steps per block; each lane prefetches PF/4 positions
+    float pre[PF / 4], cur[PF / 4];
+    unsigned prew[PF / 4];
+    // lane (line, p) loads positions t0 + 4 q + p
+    auto issue = [&](int t0) {
+#pragma unroll
+        for (int q = 0; q < PF / 4; q++) {
+            int t = t0 + 4 * q + p;
+            if (SRCMODE == 2) {
+                prew[q] = (t < n) ? sf4[(size_t)(t >> 2) * Cs] : 0x01010101u;
+                pre[q] = (t < n && img == 1) ? sd[(size_t)t * Cs] : 0.0f;
+            } else {
+                pre[q] = (t < n) ? src[(size_t)t * Cs] : 0.0f;
+            }
+        }
+    };
+    issue(0);
+
+    double s = 0.0;
+    float o_last = 0.0f;                            // this stage's output of the previous step
+    int slot = 0;
+    float old = 0.0f;
+    const int total = n + 4 * r + 3;
+    for (int m0 = 0; m0 < total; m0 += PF) {
+#pragma unroll
+        for (int q = 0; q < PF / 4; q++) {
+            if (SRCMODE == 2) {
+                bool fl = ((prew[q] >> (8 * p)) & 0xFFu) != 0;   // byte p of the word = position 4q + p
+                cur[q] = (img == 0) ? (fl ? 0.0f : 1.0f) : (fl ? 0.0f : pre[q]);
+            } else {
+                cur[q] = pre[q];
+            }
+        }
+        issue(m0 + PF);
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int m = m0 + u;
+            const int t = m - p;                    // this stage's time index
+            // sample for stage 0: position m was loaded by lane (u & 3) of the quad
+            float xs;
+            if ((u & 3) == 0) xs = dpp_quad<QUAD_PERM(0, 0, 0, 0)>(cur[u >> 2]);
+            else if ((u & 3) == 1) xs = dpp_quad<QUAD_PERM(1, 1, 1, 1)>(cur[u >> 2]);
+            else if ((u & 3) == 2) xs = dpp_quad<QUAD_PERM(2, 2, 2, 2)>(cur[u >> 2]);
+            else xs = dpp_quad<QUAD_PERM(3, 3, 3, 3)>(cur[u >> 2]);
+            // upstream stage's previous output
+            const float up = dpp_quad<QUAD_PERM(0, 0, 1, 2)>(o_last);
+            const bool act = t >= 0 && t < tend;
+            float in = (p == 0) ? xs : up;
+            in = (t >= ilo && t < ihi) ? in : 0.0f;
+            const int ns = (slot + 1 == R2) ? 0 : slot + 1;
+            const float nold = ring[ns * 64];       // next step's trailing sample (R2 >= 2)
+            if (act) {
+                ring[slot * 64] = in;
+                s += (double)in;
+                o_last = (float)s;
+                s -= (double)old;
+                old = nold;
+                slot = ns;
+                if (p == 3) {
+                    const int i = t - 4 * r;
+                    if (i >= 0 && colok) dst[(size_t)i * Cs] = DIV ? o_last / denom : o_last;
+                }
+            }
+        }
+    }
+}
+
 // r == 0 on both axes: weight = !flag, data = flag ? 0 : x (flagging.py:500-503
 // followed by the plain copy of flagging.py:465-466).
 __global__ void k_build_wo(const float* __restrict__ data, const uint8_t* __restrict__ flags,
@@ -1982,16 +2098,39 @@ int launch_median(const Run& r, const float* data, const uint8_t* flags, double*
 // LDS budget of the single-sweep filter: 4 stages x 2r slots x BT threads x 4 B.
 // Returns the block size to use, or 0 when the radius is too large and the
 // in-place multi-pass kernel must be used instead.
+// Radius limits of the single-sweep kernels.  r <= LDS_R_MAX: K4b with 256
+// threads (4 rings per thread); r <= LANE4_R_MAX: K4c (one ring per thread);
+// beyond: the in-place multi-pass kernel.
+#define LDS_R_MAX 20   // measured: 4 rings per thread win up to here (256 threads to r = 10, 128 beyond)
+#define LANE4_R_MAX 80
 int colfilter_lds_block(int rad, int C) {
     static const bool disabled = [] {
         const char* e = getenv("TRI_FILTER_MULTIPASS");
         return e && e[0] == '1';
     }();
+    static const bool no_lane4 = [] {
+        const char* e = getenv("TRI_FILTER_NO_LANE4");
+        return e && e[0] == '1';
+    }();
     if (disabled || rad <= 0) return 0;
-    int bt = rad <= 10 ? 256 : (rad <= 20 ? 128 : (rad <= 40 ? 64 : 0));
-    if (bt == 0) return 0;
-    while (bt > 64 && bt / 2 >= C) bt /= 2;
-    return bt;
+    if (no_lane4) {
+        int bt = rad <= 10 ? 256 : (rad <= 20 ? 128 : (rad <= 40 ? 64 : 0));
+        while (bt > 64 && bt / 2 >= C) bt /= 2;
+        return bt;
+    }
+    if (rad <= LDS_R_MAX) {
+        int bt = rad <= 10 ? 256 : 128;
+        while (bt > 64 && bt / 2 >= C) bt /= 2;
+        return bt;
+    }
+    return rad <= LANE4_R_MAX ? 64 : 0;
+}
+inline bool colfilter_use_lane4(int rad) {
+    static const bool no_lane4 = [] {
+        const char* e = getenv("TRI_FILTER_NO_LANE4");
+        return e && e[0] == '1';
+    }();
+    return !no_lane4 && rad > LDS_R_MAX && rad <= LANE4_R_MAX;
 }
 
 // One axis of masked_gaussian_filter's two box filters (weight image and
@@ -2010,6 +2149,45 @@ int launch_colfilter(const Run& r, int srcmode, float* bufW, float* bufO, const 
     float denom = box_denominator(rad);
     int bt = colfilter_lds_block(rad, C);
     if (deferred_denom) *deferred_denom = 0.0f;
+    if (bt > 0 && colfilter_use_lane4(rad) && !transposed_out) {
+        size_t lds = (size_t)2 * rad * 64 * sizeof(float);
+        dim3 grid((unsigned)cdiv(C, 16), (unsigned)W, 2);
+        static bool attr4 = false;
+        if (!attr4) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lane4<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lane4<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lane4<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lane4<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr4 = true;
+        }
+        if (srcmode == 0) {
+            // byte flags + data (spectrum path): build-free variant is not provided;
+            // fall through to the 4-ring kernel below when it fits, else multi-pass
+        } else if (srcmode == 2) {
+            if (!deferred_denom) return set_err(TRI_EINVAL, "internal: packed-flag filter needs a deferred denominator");
+            *deferred_denom = denom;
+            hipLaunchKernelGGL((k_colfilter_lane4<2, false>), grid, dim3(64), lds, r.st, (const float*)nullptr, (const float*)nullptr,
+                               srcData, srcFlags, dstW, dstO, n, C, rad, denom, (size_t)0, sws, dws);
+            LAUNCHCHK();
+            return TRI_OK;
+        } else if (deferred_denom) {
+            *deferred_denom = denom;
+            hipLaunchKernelGGL((k_colfilter_lane4<1, false>), grid, dim3(64), lds, r.st, (const float*)bufW, (const float*)bufO,
+                               srcData, srcFlags, dstW, dstO, n, C, rad, denom, bws, sws, dws);
+            LAUNCHCHK();
+            return TRI_OK;
+        } else {
+            hipLaunchKernelGGL((k_colfilter_lane4<1, true>), grid, dim3(64), lds, r.st, (const float*)bufW, (const float*)bufO,
+                               srcData, srcFlags, dstW, dstO, n, C, rad, denom, bws, sws, dws);
+            LAUNCHCHK();
+            return TRI_OK;
+        }
+    }
+    if (bt > 0 && colfilter_use_lane4(rad) && srcmode == 0) {
+        // spectrum path with a medium radius: 4-ring kernel with a small block if it fits
+        bt = rad <= 20 ? 128 : (rad <= 40 ? 64 : 0);
+        while (bt > 64 && bt / 2 >= C) bt /= 2;
+    }
     if (bt > 0) {
         size_t lds = (size_t)4 * 2 * rad * bt * sizeof(float);
         dim3 grid((unsigned)cdiv(C, bt), (unsigned)W, 2);
