@@ -172,6 +172,9 @@ def _np_median_abs(vals):
     (3, 1000, [0, 1000], (1, 2, 3)),
     (2, 772, [0, 772], (1,)),
     (3, 410, [0, 41, 82, 123, 410], (1, 2)),
+    (3, 4096, [0, 409, 819, 1228, 1638, 2048, 2457, 2867, 3276, 3686, 4096], (1, 4)),
+    (2, 1024, [3, 1021], (1, 4)),
+    (2, 64, [1, 2, 7, 61, 64], (1, 4)),
     (2, 4096, [0, 4, 8, 2048, 4096], (2, 3)),
     (1, 6000, [0, 1, 2, 3001, 6000], (2,)),
     (4, 64, [0, 0, 1, 2, 64], (1, 2)),

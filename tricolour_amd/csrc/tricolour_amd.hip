@@ -390,28 +390,31 @@ k_median_wave(const float* __restrict__ data, const uint8_t* __restrict__ flags,
     unsigned keys[KS];
     unsigned nloc = 0;
     if (VEC4) {
-        // contiguous, 16-byte aligned segment: float4 / uchar4 loads (a selection
-        // does not care which lane holds which sample)
+        // rows are 16-byte aligned and a multiple of 4 long: float4 / uchar4 loads
+        // of the aligned groups covering the segment, samples outside it masked
+        // (a selection does not care which lane holds which sample)
+        const int mis = live ? (int)(seg_start[g] & 3) : 0;
+        const float* d4 = d - mis;
+        const uint8_t* f4 = f - mis;
 #pragma unroll
         for (int u4 = 0; u4 < KS / 4; u4++) {
-            int i = (u4 * 64 + lane) * 4;
+            const int i = (u4 * 64 + lane) * 4;          // offset of the aligned group
             float4 dv = make_float4(0.f, 0.f, 0.f, 0.f);
             uchar4 fv = make_uchar4(1, 1, 1, 1);
-            if (i + 3 < len) {
-                dv = *reinterpret_cast<const float4*>(d + i);
-                fv = *reinterpret_cast<const uchar4*>(f + i);
-            } else if (i < len) {
-                float dd[4] = {0.f, 0.f, 0.f, 0.f};
-                unsigned char ff[4] = {1, 1, 1, 1};
-                for (int q = 0; q < 4 && i + q < len; q++) { dd[q] = d[i + q]; ff[q] = f[i + q]; }
-                dv = make_float4(dd[0], dd[1], dd[2], dd[3]);
-                fv = make_uchar4(ff[0], ff[1], ff[2], ff[3]);
+            if (i < len + mis) {
+                dv = *reinterpret_cast<const float4*>(d4 + i);
+                fv = *reinterpret_cast<const uchar4*>(f4 + i);
             }
-            keys[4 * u4 + 0] = fv.x ? SENT : (__float_as_uint(dv.x) & 0x7FFFFFFFu);
-            keys[4 * u4 + 1] = fv.y ? SENT : (__float_as_uint(dv.y) & 0x7FFFFFFFu);
-            keys[4 * u4 + 2] = fv.z ? SENT : (__float_as_uint(dv.z) & 0x7FFFFFFFu);
-            keys[4 * u4 + 3] = fv.w ? SENT : (__float_as_uint(dv.w) & 0x7FFFFFFFu);
-            nloc += (fv.x ? 0 : 1) + (fv.y ? 0 : 1) + (fv.z ? 0 : 1) + (fv.w ? 0 : 1);
+            const int j = i - mis;                         // logical index of the group's first sample
+            const bool v0 = j >= 0 && j < len && !fv.x;
+            const bool v1 = j + 1 >= 0 && j + 1 < len && !fv.y;
+            const bool v2 = j + 2 >= 0 && j + 2 < len && !fv.z;
+            const bool v3 = j + 3 >= 0 && j + 3 < len && !fv.w;
+            keys[4 * u4 + 0] = v0 ? (__float_as_uint(dv.x) & 0x7FFFFFFFu) : SENT;
+            keys[4 * u4 + 1] = v1 ? (__float_as_uint(dv.y) & 0x7FFFFFFFu) : SENT;
+            keys[4 * u4 + 2] = v2 ? (__float_as_uint(dv.z) & 0x7FFFFFFFu) : SENT;
+            keys[4 * u4 + 3] = v3 ? (__float_as_uint(dv.w) & 0x7FFFFFFFu) : SENT;
+            nloc += (v0 ? 1 : 0) + (v1 ? 1 : 0) + (v2 ? 1 : 0) + (v3 ? 1 : 0);
         }
     } else {
 #pragma unroll
@@ -2070,16 +2073,20 @@ bool st_use_fused(const StWin& sw) {
 int launch_median(const Run& r, const float* data, const uint8_t* flags, double* med, size_t WSd,
                   size_t WSf, size_t RS, size_t ES, const int64_t* seg_start,
                   const int64_t* seg_len, int R, int G, int64_t W, int64_t max_len, bool vec_ok = false,
-                  bool whole_rows = false) {
+                  bool rows_aligned = false) {
     if ((int64_t)R * G <= 0 || W <= 0) return TRI_OK;
     if ((int64_t)R * G > 0x7FFFFFFF || W > 65535) return set_err(TRI_EUNSUPPORTED, "median grid too large");
-    // whole-row segments of 4-aligned rows can be loaded 16 bytes at a time
-    const bool row4 = G == 1 && ES == 1 && RS % 4 == 0 && WSd % 4 == 0 && WSf % 4 == 0 && max_len % 4 == 0 &&
-                      ((uintptr_t)data % 16 == 0) && ((uintptr_t)flags % 4 == 0) && whole_rows;
-    if (max_len <= 64 * 8)
+    // segments of contiguous 4-aligned rows can be loaded 16 bytes at a time
+    // (misaligned segment ends are masked, costing up to 3 extra slots)
+    const bool row4 = ES == 1 && RS % 4 == 0 && WSd % 4 == 0 && WSf % 4 == 0 &&
+                      ((uintptr_t)data % 16 == 0) && ((uintptr_t)flags % 4 == 0) && rows_aligned;
+    if (max_len + 3 <= 64 * 8 && row4)
+        hipLaunchKernelGGL((k_median_wave<8, true>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)W), dim3(256), 0, r.st,
+                           data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
+    else if (max_len <= 64 * 8)
         hipLaunchKernelGGL((k_median_wave<8, false>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)W), dim3(256), 0, r.st,
                            data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
-    else if (max_len <= 64 * MW_K && row4)
+    else if (max_len + 3 <= 64 * MW_K && row4)
         hipLaunchKernelGGL((k_median_wave<MW_K, true>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)W), dim3(256), 0, r.st,
                            data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
     else if (max_len <= 64 * MW_K)
@@ -2555,7 +2562,7 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
     // MAD per (time, chunk) = contiguous row segments of the TF layout.
     rc = launch_u8<1>(r, ws.tflTF, ws.flagsTF, N, N, N, W);
     if (rc) return rc;
-    rc = launch_median(r, residTF, ws.flagsTF, ws.med, N, N, (size_t)Fa, 1, ws.segC_start, ws.segC_len, T, G, W, pl.maxchunk);
+    rc = launch_median(r, residTF, ws.flagsTF, ws.med, N, N, (size_t)Fa, 1, ws.segC_start, ws.segC_len, T, G, W, pl.maxchunk, false, Fa % 4 == 0);
     if (rc) return rc;
     rc = launch_colst(r, pl.swF, residFT, ws.med, ws.fflFT, ws.d_chunk_ends, Fa, T, G, wsB, N, W);
     if (rc) return rc;
@@ -2841,12 +2848,17 @@ extern "C" int tri_test_median(const float* data, const uint8_t* flags, double* 
     size_t WS = (size_t)rows * row_len, RS = (size_t)row_len;
     int R = (int)rows;
     if (variant == 0) variant = maxlen <= 64 * MW_K ? 1 : (al4 ? 3 : 2);
-    if (variant == 1 && maxlen > 64 * MW_K) return set_err(TRI_EINVAL, "wave kernel handles segments <= 1024");
+    if ((variant == 1 || variant == 4) && maxlen > 64 * MW_K) return set_err(TRI_EINVAL, "wave kernel handles segments <= 1024");
+    if (variant == 4 && (row_len % 4 != 0 || maxlen + 3 > 64 * MW_K)) return set_err(TRI_EINVAL, "masked vector variant needs row_len % 4 == 0 and segments <= 1021");
     if (variant == 3 && !al4) return set_err(TRI_EINVAL, "vector loads need 4-aligned segments");
     if (variant == 1 && maxlen <= 64 * 8)
         hipLaunchKernelGGL((k_median_wave<8, false>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)n_win), dim3(256), 0, st,
                            data, flags, med, WS, WS, RS, (size_t)1, d_start, d_len, R, G);
-    else if (variant == 1 && G == 1 && al4 && seg_ends[0] == 0 && seg_ends[1] == row_len)
+    else if (variant == 4 && row_len % 4 == 0 && maxlen + 3 <= 64 * 8)
+        hipLaunchKernelGGL((k_median_wave<8, true>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)n_win), dim3(256), 0, st,
+                           data, flags, med, WS, WS, RS, (size_t)1, d_start, d_len, R, G);
+    else if ((variant == 4 && row_len % 4 == 0 && maxlen + 3 <= 64 * MW_K) ||
+             (variant == 1 && G == 1 && al4 && seg_ends[0] == 0 && seg_ends[1] == row_len))
         hipLaunchKernelGGL((k_median_wave<MW_K, true>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)n_win), dim3(256), 0, st,
                            data, flags, med, WS, WS, RS, (size_t)1, d_start, d_len, R, G);
     else if (variant == 1)
