@@ -313,3 +313,36 @@ def test_size_independent_properties_at_slab_scale(gpu):
     assert bool(a[nanmask].all())
     allflag = a[5] & ~nanmask[5]
     assert not bool(allflag.any())
+
+
+def test_concurrent_calls_from_threads(gpu, oracle):
+    """The reference is called from a dask ThreadPool (app.py:266-271): the
+    library must be re-entrant (per-thread workspaces, no global state)."""
+    import threading
+    rs = np.random.RandomState(21)
+    shape = (2, 2, 48, 96)
+    cases = []
+    for k in range(6):
+        vis = (rs.standard_normal(shape) + 1j * rs.standard_normal(shape)).astype(np.complex64)
+        vis[..., 10 + 7 * k] *= 6
+        flags = rs.uniform(size=shape) < 0.03
+        kw = dict(num_major_iterations=1 + k % 2, background_iterations=1 + k % 3)
+        cases.append((vis, flags, kw, oracle.sum_threshold_flagger(vis, flags, **kw)))
+    results = [None] * len(cases)
+    errors = []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                results[i] = gpu.sum_threshold_flagger(cases[i][0], cases[i][1], **cases[i][2])
+        except Exception as e:   # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(cases))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i, c in enumerate(cases):
+        assert np.array_equal(results[i], c[3]), "thread %d" % i

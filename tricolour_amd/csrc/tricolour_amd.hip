@@ -2159,14 +2159,15 @@ int launch_colfilter(const Run& r, int srcmode, float* bufW, float* bufO, const 
     if (bt > 0 && colfilter_use_lane4(rad) && !transposed_out) {
         size_t lds = (size_t)2 * rad * 64 * sizeof(float);
         dim3 grid((unsigned)cdiv(C, 16), (unsigned)W, 2);
-        static bool attr4 = false;
-        if (!attr4) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lane4<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lane4<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lane4<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lane4<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr4 = true;
-        }
+        // thread-safe one-time setup (C++11 static initialisation)
+        static const hipError_t attr4 = [] {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lane4<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lane4<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lane4<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lane4<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            return e;
+        }();
+        HIPCHK(attr4);
         if (srcmode == 0) {
             // byte flags + data (spectrum path): build-free variant is not provided;
             // fall through to the 4-ring kernel below when it fits, else multi-pass
@@ -2198,20 +2199,16 @@ int launch_colfilter(const Run& r, int srcmode, float* bufW, float* bufO, const 
     if (bt > 0) {
         size_t lds = (size_t)4 * 2 * rad * bt * sizeof(float);
         dim3 grid((unsigned)cdiv(C, bt), (unsigned)W, 2);
-        static bool attr_set = false;
-        if (!attr_set) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<0, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<1, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<1, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
+        static const hipError_t attr_set = [] {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<0, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<1, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<1, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<2, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            return e;
+        }();
+        HIPCHK(attr_set);
         if (srcmode == 2) {
-            static bool attr2 = false;
-            if (!attr2) {
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<2, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr2 = true;
-            }
             if (deferred_denom) *deferred_denom = denom;
             else return set_err(TRI_EINVAL, "internal: packed-flag filter needs a deferred denominator");
             hipLaunchKernelGGL((k_colfilter_lds<2, false, false>), grid, dim3(bt), lds, r.st, (const float*)nullptr, (const float*)nullptr,
