@@ -837,6 +837,133 @@ k_colfilter_lds(const float* __restrict__ srcW, const float* __restrict__ srcO,
 }
 
 // ---------------------------------------------------------------------------
+// K4b'  Single-sweep box filter (K4b) whose INPUT images are stored
+// transposed: line c is row c of an [C][ld] array (so the time-axis stage's TF
+// output feeds the frequency-axis stage without a transpose pass).  Each
+// workgroup (128 lines) stages 32 line positions at a time through an LDS
+// tile: global loads are 128-byte row segments (coalesced along the line),
+// the tile is read back column-wise, one value per thread and step.  The
+// arithmetic is that of K4b.  grid (ceil(C/128), W, 2 images), block 128,
+// dynamic LDS: 4 * 2r * 128 floats (rings) + 32 * 129 floats (tile)
+// ---------------------------------------------------------------------------
+#define CFT_BT 128
+#define CFT_PF 32
+template <bool DIV>
+__global__ void __launch_bounds__(CFT_BT)
+k_colfilter_lds_t(const float* __restrict__ srcW, const float* __restrict__ srcO,
+                  float* __restrict__ dstW, float* __restrict__ dstO,
+                  int n, int C, int ld, int r, float denom, size_t sws_img, size_t dws) {
+    extern __shared__ float cf_ring[];
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * CFT_BT;
+    const int c = c0 + tid;
+    const bool colok = c < C;
+    const size_t win = blockIdx.y;
+    const int img = blockIdx.z;
+    const int R2 = 2 * r;
+    const size_t Cs = (size_t)C;
+    const float* src = (img == 0 ? srcW : srcO) + win * sws_img;
+    float* dst = (img == 0 ? dstW : dstO) + win * dws + (colok ? c : 0);
+    float* ring = cf_ring + tid;                                 // element (p, slot) at ((p*R2)+slot)*BT
+    float* tile = cf_ring + (size_t)4 * R2 * CFT_BT;             // [CFT_PF][CFT_BT + 1]
+    for (int k = 0; k < 4 * R2; k++) ring[(size_t)k * CFT_BT] = 0.0f;
+
+    // staging: element e = j * 128 + tid of a [128 lines][32 positions] patch:
+    // line = e / 32, position = e % 32  ->  lanes 0..31 read 128 contiguous bytes
+    const int s_pos = tid & 31;
+    const int s_line0 = tid >> 5;                                // + 4 j
+    float pre[CFT_PF], cur[CFT_PF];
+    auto issue = [&](int t0) {
+#pragma unroll
+        for (int j = 0; j < CFT_PF; j++) {
+            int line = c0 + 4 * j + s_line0;
+            int t = t0 + s_pos;
+            pre[j] = (line < C && t < n) ? src[(size_t)line * ld + t] : 0.0f;
+        }
+    };
+    // registers -> LDS tile (transposed) -> this thread's 32 samples
+    auto exchange = [&]() {
+        __syncthreads();                                         // previous tile fully consumed
+#pragma unroll
+        for (int j = 0; j < CFT_PF; j++) tile[s_pos * (CFT_BT + 1) + 4 * j + s_line0] = pre[j];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < CFT_PF; u++) cur[u] = tile[u * (CFT_BT + 1) + tid];
+    };
+
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0;
+    float o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;
+    int slot1 = 0, slot2 = 0, slot3 = 0, slot4 = 0;
+    float* rp1 = ring;
+    float* rp2 = ring + (size_t)(1 * R2) * CFT_BT;
+    float* rp3 = ring + (size_t)(2 * R2) * CFT_BT;
+    float* rp4 = ring + (size_t)(3 * R2) * CFT_BT;
+    float old1 = 0.0f, old2 = 0.0f, old3 = 0.0f, old4 = 0.0f;
+    auto nextslot = [&](int sl) { return (sl + 1 == R2) ? 0 : sl + 1; };
+    const int total = n + 4 * r + 3;
+
+    auto step = [&](auto fastc, const int m, const float xin) {
+        constexpr bool FAST = decltype(fastc)::value;
+        const bool a4 = FAST || (m - 3 >= 0 && m - 3 < n + 4 * r);
+        const bool a3 = FAST || (m - 2 >= 0 && m - 2 < n + 4 * r);
+        const bool a2 = FAST || (m - 1 >= 0 && m - 1 < n + 4 * r);
+        const bool a1 = FAST || (m < n + R2);
+        const int ns1 = a1 ? nextslot(slot1) : slot1, ns2 = a2 ? nextslot(slot2) : slot2;
+        const int ns3 = a3 ? nextslot(slot3) : slot3, ns4 = a4 ? nextslot(slot4) : slot4;
+        const float nold1 = rp1[(size_t)ns1 * CFT_BT], nold2 = rp2[(size_t)ns2 * CFT_BT];
+        const float nold3 = rp3[(size_t)ns3 * CFT_BT], nold4 = rp4[(size_t)ns4 * CFT_BT];
+        if (a4) {
+            const int t = m - 3;
+            float in = (FAST || t >= R2) ? o3 : 0.0f;
+            rp4[(size_t)slot4 * CFT_BT] = in;
+            s4 += (double)in;
+            float out = (float)s4;
+            s4 -= (double)old4;
+            int i = t - 4 * r;
+            if ((FAST || i >= 0) && colok) dst[(size_t)i * Cs] = DIV ? out / denom : out;
+        }
+        if (a3) {
+            float in = o2;
+            rp3[(size_t)slot3 * CFT_BT] = in;
+            s3 += (double)in;
+            o3 = (float)s3;
+            s3 -= (double)old3;
+        }
+        if (a2) {
+            float in = (FAST || m - 1 < n + R2) ? o1 : 0.0f;
+            rp2[(size_t)slot2 * CFT_BT] = in;
+            s2 += (double)in;
+            o2 = (float)s2;
+            s2 -= (double)old2;
+        }
+        if (a1) {
+            float in = (FAST || m < n) ? xin : 0.0f;
+            rp1[(size_t)slot1 * CFT_BT] = in;
+            s1 += (double)in;
+            o1 = (float)s1;
+            s1 -= (double)old1;
+        }
+        if (a1) { old1 = nold1; slot1 = ns1; }
+        if (a2) { old2 = nold2; slot2 = ns2; }
+        if (a3) { old3 = nold3; slot3 = ns3; }
+        if (a4) { old4 = nold4; slot4 = ns4; }
+    };
+
+    issue(0);
+    for (int m0 = 0; m0 < total; m0 += CFT_PF) {
+        exchange();                 // tile of positions [m0, m0 + 32) -> cur[]
+        issue(m0 + CFT_PF);         // next tile's loads stay in flight during the arithmetic
+        if (m0 >= 4 * r + 3 && m0 + CFT_PF <= n) {
+#pragma unroll
+            for (int u = 0; u < CFT_PF; u++) step(std::true_type{}, m0 + u, cur[u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < CFT_PF; u++) step(std::false_type{}, m0 + u, cur[u]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K4c  "Lane-per-stage" form of the single-sweep box filter for medium radii
 // (the four 2r-deep delay lines of K4b no longer fit LDS at useful occupancy):
 // the four cascade stages of one line run in the four lanes of a quad, every
@@ -2073,20 +2200,21 @@ bool st_use_fused(const StWin& sw) {
 int launch_median(const Run& r, const float* data, const uint8_t* flags, double* med, size_t WSd,
                   size_t WSf, size_t RS, size_t ES, const int64_t* seg_start,
                   const int64_t* seg_len, int R, int G, int64_t W, int64_t max_len, bool vec_ok = false,
-                  bool rows_aligned = false) {
+                  bool rows_aligned = false, bool segs_aligned = false) {
     if ((int64_t)R * G <= 0 || W <= 0) return TRI_OK;
     if ((int64_t)R * G > 0x7FFFFFFF || W > 65535) return set_err(TRI_EUNSUPPORTED, "median grid too large");
     // segments of contiguous 4-aligned rows can be loaded 16 bytes at a time
     // (misaligned segment ends are masked, costing up to 3 extra slots)
     const bool row4 = ES == 1 && RS % 4 == 0 && WSd % 4 == 0 && WSf % 4 == 0 &&
                       ((uintptr_t)data % 16 == 0) && ((uintptr_t)flags % 4 == 0) && rows_aligned;
-    if (max_len + 3 <= 64 * 8 && row4)
+    const int64_t slack = segs_aligned ? 0 : 3;   // misaligned segment starts cost up to 3 masked slots
+    if (max_len + slack <= 64 * 8 && row4)
         hipLaunchKernelGGL((k_median_wave<8, true>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)W), dim3(256), 0, r.st,
                            data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
     else if (max_len <= 64 * 8)
         hipLaunchKernelGGL((k_median_wave<8, false>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)W), dim3(256), 0, r.st,
                            data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
-    else if (max_len + 3 <= 64 * MW_K && row4)
+    else if (max_len + slack <= 64 * MW_K && row4)
         hipLaunchKernelGGL((k_median_wave<MW_K, true>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)W), dim3(256), 0, r.st,
                            data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
     else if (max_len <= 64 * MW_K)
@@ -2165,6 +2293,7 @@ int launch_colfilter(const Run& r, int srcmode, float* bufW, float* bufO, const 
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lane4<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lane4<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lane4<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lane4<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             return e;
         }();
         HIPCHK(attr4);
@@ -2172,10 +2301,14 @@ int launch_colfilter(const Run& r, int srcmode, float* bufW, float* bufO, const 
             // byte flags + data (spectrum path): build-free variant is not provided;
             // fall through to the 4-ring kernel below when it fits, else multi-pass
         } else if (srcmode == 2) {
-            if (!deferred_denom) return set_err(TRI_EINVAL, "internal: packed-flag filter needs a deferred denominator");
-            *deferred_denom = denom;
-            hipLaunchKernelGGL((k_colfilter_lane4<2, false>), grid, dim3(64), lds, r.st, (const float*)nullptr, (const float*)nullptr,
-                               srcData, srcFlags, dstW, dstO, n, C, rad, denom, (size_t)0, sws, dws);
+            if (deferred_denom) {
+                *deferred_denom = denom;
+                hipLaunchKernelGGL((k_colfilter_lane4<2, false>), grid, dim3(64), lds, r.st, (const float*)nullptr, (const float*)nullptr,
+                                   srcData, srcFlags, dstW, dstO, n, C, rad, denom, (size_t)0, sws, dws);
+            } else {
+                hipLaunchKernelGGL((k_colfilter_lane4<2, true>), grid, dim3(64), lds, r.st, (const float*)nullptr, (const float*)nullptr,
+                                   srcData, srcFlags, dstW, dstO, n, C, rad, denom, (size_t)0, sws, dws);
+            }
             LAUNCHCHK();
             return TRI_OK;
         } else if (deferred_denom) {
@@ -2205,14 +2338,19 @@ int launch_colfilter(const Run& r, int srcmode, float* bufW, float* bufO, const 
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<1, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<2, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<2, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             return e;
         }();
         HIPCHK(attr_set);
         if (srcmode == 2) {
-            if (deferred_denom) *deferred_denom = denom;
-            else return set_err(TRI_EINVAL, "internal: packed-flag filter needs a deferred denominator");
-            hipLaunchKernelGGL((k_colfilter_lds<2, false, false>), grid, dim3(bt), lds, r.st, (const float*)nullptr, (const float*)nullptr,
-                               srcData, srcFlags, dstW, dstO, n, C, rad, denom, (size_t)0, sws, dws);
+            if (deferred_denom) {
+                *deferred_denom = denom;
+                hipLaunchKernelGGL((k_colfilter_lds<2, false, false>), grid, dim3(bt), lds, r.st, (const float*)nullptr, (const float*)nullptr,
+                                   srcData, srcFlags, dstW, dstO, n, C, rad, denom, (size_t)0, sws, dws);
+            } else {
+                hipLaunchKernelGGL((k_colfilter_lds<2, true, false>), grid, dim3(bt), lds, r.st, (const float*)nullptr, (const float*)nullptr,
+                                   srcData, srcFlags, dstW, dstO, n, C, rad, denom, (size_t)0, sws, dws);
+            }
             LAUNCHCHK();
             return TRI_OK;
         }
@@ -2317,6 +2455,34 @@ int launch_sub(const Run& r, const float* a, const float* b, float* out, size_t 
     return TRI_OK;
 }
 
+// Frequency-axis stage reading the time-axis stage's TF images directly
+// (k_colfilter_lds_t).  Usable for radii whose four rings fit LDS at 128 threads.
+bool colfilter_t_usable(int rad) {
+    static const bool off = [] { const char* e = getenv("TRI_FILTER_NO_TIN"); return e && e[0] == '1'; }();
+    return !off && rad > 0 && rad <= 16;
+}
+
+int launch_colfilter_t(const Run& r, const float* srcW, const float* srcO, float* dstW, float* dstO,
+                       int n, int C, int ld, int rad, size_t sws_img, size_t dws, int64_t W, float* deferred_denom) {
+    float denom = box_denominator(rad);
+    size_t lds = ((size_t)4 * 2 * rad * CFT_BT + (size_t)CFT_PF * (CFT_BT + 1)) * sizeof(float);
+    static const hipError_t attr = [] {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds_t<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds_t<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return e;
+    }();
+    HIPCHK(attr);
+    dim3 grid((unsigned)cdiv(C, CFT_BT), (unsigned)W, 2);
+    if (deferred_denom) {
+        *deferred_denom = denom;
+        hipLaunchKernelGGL(k_colfilter_lds_t<false>, grid, dim3(CFT_BT), lds, r.st, srcW, srcO, dstW, dstO, n, C, ld, rad, denom, sws_img, dws);
+    } else {
+        hipLaunchKernelGGL(k_colfilter_lds_t<true>, grid, dim3(CFT_BT), lds, r.st, srcW, srcO, dstW, dstO, n, C, ld, rad, denom, sws_img, dws);
+    }
+    LAUNCHCHK();
+    return TRI_OK;
+}
+
 // _get_background2d (flagging.py:516-579) for the median spectra of the batch,
 // held in spectrum layout [Fa][Wb] (line axis = channel, column = window).
 // Result: rows [0,Fa) of ws.so hold the background.
@@ -2395,11 +2561,14 @@ int background2d(const Run& r) {
         static const bool prebuild = [] { const char* e = getenv("TRI_TIME_PREBUILD"); return !(e && e[0] == '0'); }();
         float den_t = 0.0f, den_f = 0.0f;   // divisions deferred to the transposes / masked_div
         bool direct_ft = false;
+        // frequency stage able to read the time stage's TF images itself (no transposes)
+        const bool tin = colfilter_t_usable(r1);
+        float* den_t_ptr = tin ? nullptr : &den_t;
         // (for the in-place multi-pass kernel, used at large radii, building on
         //  the fly measured faster: 11.4 vs 16.8 ms per call at 128 windows)
         if (r0 > 0 && packed && colfilter_lds_block(r0, Fa) > 0) {
             // single sweep straight from (data, packed flags): no image build
-            rc = launch_colfilter(r, 2, ws.Aw, ws.Ao, ws.dataTF, ws.bgfTF, ws.Aw, ws.Ao, T, Fa, r0, wsA, N, wsA, W, &den_t);
+            rc = launch_colfilter(r, 2, ws.Aw, ws.Ao, ws.dataTF, ws.bgfTF, ws.Aw, ws.Ao, T, Fa, r0, wsA, N, wsA, W, den_t_ptr);
             if (rc) return rc;
         } else if (r0 > 0 && !packed && prebuild && colfilter_lds_block(r0, Fa) > 0) {
             const bool lds_path = true;
@@ -2417,7 +2586,7 @@ int background2d(const Run& r) {
                 size_t off2 = colfilter_lds_block(r1, T) > 0 ? 0 : (size_t)4 * r1 * T;
                 rc = launch_colfilter(r, 1, ws.Aw, ws.Ao, nullptr, nullptr, ws.Bw + off2, ws.Bo + off2, T, Fa, r0, wsA, 0, wsB, W, nullptr, true);
             } else {
-                rc = launch_colfilter(r, 1, ws.Aw, ws.Ao, nullptr, nullptr, ws.Aw, ws.Ao, T, Fa, r0, wsA, 0, wsA, W, &den_t);
+                rc = launch_colfilter(r, 1, ws.Aw, ws.Ao, nullptr, nullptr, ws.Aw, ws.Ao, T, Fa, r0, wsA, 0, wsA, W, den_t_ptr);
             }
             if (rc) return rc;
         } else if (r0 > 0) {
@@ -2442,14 +2611,17 @@ int background2d(const Run& r) {
         // --- to FT layout: rows [4 r1, 4 r1 + Fa) of the padded buffers for the
         //     in-place multi-pass filter, rows [0, Fa) for the single-sweep one ---
         size_t off = colfilter_lds_block(r1, T) > 0 ? 0 : (size_t)4 * r1 * T;
-        if (!direct_ft) {
+        if (tin && !direct_ft) {
+            rc = launch_colfilter_t(r, ws.Aw, ws.Ao, ws.Bw, ws.Bo, Fa, T, Fa, r1, wsA, wsB, W, &den_f);
+            if (rc) return rc;
+        } else if (!direct_ft) {
             rc = launch_transpose<float>(r, ws.Aw, ws.Bw + off, T, Fa, wsA, wsB, W, den_t);
             if (rc) return rc;
             rc = launch_transpose<float>(r, ws.Ao, ws.Bo + off, T, Fa, wsA, wsB, W, den_t);
             if (rc) return rc;
         }
         // --- frequency axis (FT layout: line = channel, column = time) ---
-        if (r1 > 0) {
+        if (r1 > 0 && !(tin && !direct_ft)) {
             rc = launch_colfilter(r, 1, ws.Bw, ws.Bo, nullptr, nullptr, ws.Bw, ws.Bo, Fa, T, r1, wsB, 0, wsB, W, &den_f);
             if (rc) return rc;
         }
@@ -2508,7 +2680,7 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
     if (rc) return rc;
 
     // flagging.py:944  _time_median: rows of the FT layout are contiguous in time
-    rc = launch_median(r, ws.dataFT, ws.flagsFT, ws.med, N, N, (size_t)T, 1, ws.segT_start, ws.segT_len, Fa, 1, W, pl.T, false, true);
+    rc = launch_median(r, ws.dataFT, ws.flagsFT, ws.med, N, N, (size_t)T, 1, ws.segT_start, ws.segT_len, Fa, 1, W, pl.T, false, T % 4 == 0, true);
     if (rc) return rc;
     hipLaunchKernelGGL(k_spec_from_med, dim3((unsigned)cdiv((size_t)Fa * Wn, 256)), dim3(256), 0, r.st, ws.med, ws.sdata, ws.sflags, Fa, Wn);
     LAUNCHCHK();
@@ -2550,7 +2722,7 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
     // contiguous rows of the FT layout; flags = input | spectral flags.
     rc = launch_transpose<uint8_t>(r, ws.flagsTF, ws.flagsFT, T, Fa, N, N, W);
     if (rc) return rc;
-    rc = launch_median(r, residFT, ws.flagsFT, ws.med, wsB, N, (size_t)T, 1, ws.segT_start, ws.segT_len, Fa, 1, W, pl.T, false, true);
+    rc = launch_median(r, residFT, ws.flagsFT, ws.med, wsB, N, (size_t)T, 1, ws.segT_start, ws.segT_len, Fa, 1, W, pl.T, false, T % 4 == 0, true);
     if (rc) return rc;
     rc = launch_colst(r, pl.swT, residTF, ws.med, ws.tflTF, ws.d_tends, T, Fa, 1, N, N, W);
     if (rc) return rc;
