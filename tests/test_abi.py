@@ -103,6 +103,6 @@ def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "tricolour_amd")
     for dirpath, _dirs, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".h", ".cpp")):
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.lower().replace("# oracle", ""), os.path.join(dirpath, f)

@@ -11,7 +11,10 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtricolour_amd.so")
-SOURCES = [os.path.join(_HERE, "csrc", "tricolour_amd.hip")]
+SOURCES = [os.path.join(_HERE, "csrc", "tricolour_amd.hip")]   # one translation unit
+DEPENDS = [os.path.join(_HERE, "csrc", f) for f in (
+    "tri_common.hpp", "kernels_elementwise.hpp", "kernels_median.hpp", "kernels_boxfilter.hpp",
+    "kernels_sumthreshold.hpp")]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "tricolour_amd.h")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17",
@@ -52,7 +55,7 @@ def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(s) > t for s in SOURCES + [HEADER])
+    return any(os.path.getmtime(s) > t for s in SOURCES + DEPENDS + [HEADER])
 
 
 def build(force=False, verbose=False):

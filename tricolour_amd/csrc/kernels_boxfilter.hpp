@@ -1,0 +1,556 @@
+// kernels_boxfilter.hpp -- the box-Gaussian filter in its four forms (in-place multi-pass, single sweep, transposed-input single sweep, lane-per-stage)
+// Part of the single translation unit tricolour_amd.hip (see there for the overview).
+#pragma once
+
+// ---------------------------------------------------------------------------
+// K4  _box_gaussian_filter1d (flagging.py:362-419) along the line axis of a
+// [n][C] array, one thread per (column, image): four running box sums of
+// width 2r+1 over a left-zero-padded line, float64 accumulator, every pass
+// stored as float32 -- in exactly the reference's order (add the leading
+// sample, store, subtract the trailing sample).  The padded line lives in a
+// global scratch buffer buf[P = n + 4r][C] and the passes run in place, as in
+// the reference; the never-written zero padding is synthesised instead of
+// stored (rows below lo_p read as 0).
+//   SRCMODE 0: pass 1 builds weight = !flag / data = flag ? 0 : x on the fly
+//              from (srcData, srcFlags) (masked_gaussian_filter,
+//              flagging.py:500-503).
+//   SRCMODE 1: the unfiltered images were already written into rows
+//              [4r, 4r+n) of bufW / bufO (by the transposing copy).
+// Pass 4 divides by float32(d)**4 (host-computed, square-and-multiply as
+// numba does) and writes rows [0,n) of dstW / dstO.
+// grid (ceil(C/BLK), W, 2 images), block BLK
+// ---------------------------------------------------------------------------
+#define CF_U 8
+template <int SRCMODE>
+__global__ void __launch_bounds__(256)
+k_colfilter(float* __restrict__ bufW, float* __restrict__ bufO,
+            const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags,
+            float* __restrict__ dstW, float* __restrict__ dstO,
+            int n, int C, int r, float denom, size_t bws, size_t sws, size_t dws) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    size_t win = blockIdx.y;
+    const int img = blockIdx.z;  // 0 = weight image, 1 = data image
+    float* buf = (img == 0 ? bufW : bufO) + win * bws + c;
+    float* dst = (img == 0 ? dstW : dstO) + win * dws + c;
+    const float* sd = SRCMODE == 0 ? srcData + win * sws + c : nullptr;
+    const uint8_t* sf = SRCMODE == 0 ? srcFlags + win * sws + c : nullptr;
+    const int R2 = 2 * r, R4 = 4 * r;
+    const int P = n + R4;
+    const size_t Cs = (size_t)C;
+
+    auto rd = [&](int j, int p) -> float {
+        // value of padded[j] as seen by pass p (j in [0, P))
+        if (p == 1) {
+            int jj = j - R4;
+            if (jj < 0) return 0.0f;
+            if (SRCMODE == 0) {
+                bool fl = sf[(size_t)jj * Cs] != 0;
+                if (img == 0) return fl ? 0.0f : 1.0f;
+                return fl ? 0.0f : sd[(size_t)jj * Cs];
+            }
+            return buf[(size_t)j * Cs];
+        }
+        if (p == 2 && j < R2) return 0.0f;
+        return buf[(size_t)j * Cs];
+    };
+
+    for (int p = 1; p <= 4; p++) {
+        double s = 0.0;
+        if (p >= 3) {
+            // flagging.py:404-405: pre-add padded[prev_start .. start + 2r)
+            int i = 0;
+            for (; i + CF_U <= R2; i += CF_U) {
+                float v[CF_U];
+#pragma unroll
+                for (int u = 0; u < CF_U; u++) v[u] = rd(i + u, p);
+#pragma unroll
+                for (int u = 0; u < CF_U; u++) s += (double)v[u];
+            }
+            for (; i < R2; i++) s += (double)rd(i, p);
+        }
+        const int start = (p == 1) ? R2 : 0;
+        const int stop = (p == 4) ? n : (p == 3 ? n + R2 : P);
+        const int tail = n + R2;
+        const int mainEnd = min(tail, stop);
+        int i = start;
+        for (; i + CF_U <= mainEnd; i += CF_U) {
+            float lead[CF_U], prev[CF_U], o[CF_U];
+#pragma unroll
+            for (int u = 0; u < CF_U; u++) lead[u] = rd(i + u + R2, p);
+#pragma unroll
+            for (int u = 0; u < CF_U; u++) prev[u] = rd(i + u, p);
+#pragma unroll
+            for (int u = 0; u < CF_U; u++) {
+                s += (double)lead[u];
+                o[u] = (float)s;
+                s -= (double)prev[u];
+            }
+            if (p < 4) {
+#pragma unroll
+                for (int u = 0; u < CF_U; u++) buf[(size_t)(i + u) * Cs] = o[u];
+            } else {
+#pragma unroll
+                for (int u = 0; u < CF_U; u++) dst[(size_t)(i + u) * Cs] = o[u] / denom;
+            }
+        }
+        for (; i < mainEnd; i++) {
+            float lead = rd(i + R2, p);
+            float prev = rd(i, p);
+            s += (double)lead;
+            float o = (float)s;
+            s -= (double)prev;
+            if (p < 4) buf[(size_t)i * Cs] = o;
+            else dst[(size_t)i * Cs] = o / denom;
+        }
+        // flagging.py:412-416 (no leading sample left)
+        for (i = mainEnd; i < stop; i++) {
+            float prev = rd(i, p);
+            float o = (float)s;
+            s -= (double)prev;
+            if (p < 4) buf[(size_t)i * Cs] = o;
+            else dst[(size_t)i * Cs] = o / denom;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K4b  Single-sweep variant of the box filter for moderate radii: the four
+// passes run as a cascade of causal running sums in ONE pass over the line
+// (HBM traffic: one read and one write per image sample), with each stage's
+// 2r-deep delay line in LDS ([stage][slot][thread], conflict-free).
+//
+// Equivalence with the in-place passes of flagging.py:394-417 (t = causal
+// index, in_p = input stream of pass p, zero where the reference's padded
+// array holds padding or was never written):
+//     s_p += in_p[t];  out_p[t] = f32(s_p);  s_p -= in_p[t - 2r]
+// with in_1 = data (t in [0,n)), in_2 = out_1 (t in [0,n+2r)), in_3 = out_2
+// (t in [0,n+4r)), in_4 = out_3 restricted to t >= 2r (the reference never
+// forms padded_3 below index 0), result y[i] = out_4[i + 4r] / f32(d)**4.
+// Adding / subtracting the synthesised zeros is exact, so every float64
+// value equals the reference's.  Stage p+1 runs one step behind stage p so
+// the four float64 chains of a step are independent.
+// grid (ceil(C/BT), W, 2 images), block BT, dynamic LDS 4 * 2r * BT floats
+// ---------------------------------------------------------------------------
+template <int SRCMODE, bool DIV, bool TOUT>
+__global__ void __launch_bounds__(256)
+k_colfilter_lds(const float* __restrict__ srcW, const float* __restrict__ srcO,
+                const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags,
+                float* __restrict__ dstW, float* __restrict__ dstO,
+                int n, int C, int r, float denom, size_t sws_img, size_t sws, size_t dws) {
+    extern __shared__ float cf_ring[];
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const size_t win = blockIdx.y;
+    const int img = blockIdx.z;
+    const int BT = blockDim.x;
+    const int R2 = 2 * r;
+    const size_t Cs = (size_t)C;
+    const float* src = SRCMODE == 1 ? ((img == 0 ? srcW : srcO) + win * sws_img + c) : nullptr;
+    const float* sd = SRCMODE != 1 ? srcData + win * sws + c : nullptr;
+    const uint8_t* sf = SRCMODE == 0 ? srcFlags + win * sws + c : nullptr;
+    // SRCMODE 2: flags packed four line positions per 32-bit word, [n/4][C]
+    // words (byte k of word q = flag of position 4q + k): one coalesced dword
+    // load per four steps instead of a byte load per step
+    const unsigned* sf4 = SRCMODE == 2 ? reinterpret_cast<const unsigned*>(srcFlags) + win * (sws / 4) + c : nullptr;
+    // TOUT: the output is written TRANSPOSED -- line c becomes row c of an
+    // [C][n] image (n % 4 == 0) -- four consecutive outputs per 16-byte store,
+    // so the frequency-axis stage can consume it without a transpose pass.
+    float* dst = (img == 0 ? dstW : dstO) + win * dws + (TOUT ? (size_t)c * n : (size_t)c);
+    float tacc0 = 0.0f, tacc1 = 0.0f, tacc2 = 0.0f;
+    float* ring = cf_ring + threadIdx.x;            // element (p, slot) at ((p*R2)+slot)*BT
+    for (int k = 0; k < 4 * R2; k++) ring[(size_t)k * BT] = 0.0f;
+
+    auto load = [&](int t) -> float {
+        if (SRCMODE == 0) {
+            bool fl = sf[(size_t)t * Cs] != 0;
+            if (img == 0) return fl ? 0.0f : 1.0f;
+            return fl ? 0.0f : sd[(size_t)t * Cs];
+        }
+        if (SRCMODE == 2) {
+            unsigned wq = sf4[(size_t)(t >> 2) * Cs];
+            bool fl = ((wq >> (8 * (t & 3))) & 0xFFu) != 0;
+            if (img == 0) return fl ? 0.0f : 1.0f;
+            return fl ? 0.0f : sd[(size_t)t * Cs];
+        }
+        return src[(size_t)t * Cs];
+    };
+
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0;
+    float o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;       // stage outputs of the previous step
+    int slot1 = 0, slot2 = 0, slot3 = 0, slot4 = 0;
+    const int total = n + 4 * r + 3;
+    // Deep prefetch: with the LDS rings capping occupancy at 2 waves / SIMD,
+    // bytes in flight (Little's law against ~2 us of HBM latency) come from
+    // per-thread loads, not from thread count.
+    constexpr int PF = 32;
+    float pre[PF], cur[PF];
+    unsigned prew[PF / 4];   // SRCMODE 2: raw packed-flag words in flight with pre[]
+    // issue the loads of samples [t0, t0 + PF); the values are only consumed one
+    // block later, so the loads stay in flight across a block of arithmetic
+    auto issue = [&](int t0) {
+        if (SRCMODE == 2) {
+#pragma unroll
+            for (int q = 0; q < PF / 4; q++) {
+                int t = t0 + 4 * q;
+                prew[q] = (t < n) ? sf4[(size_t)(t >> 2) * Cs] : 0x01010101u;
+            }
+            if (img == 1) {
+#pragma unroll
+                for (int u = 0; u < PF; u++) {
+                    int t = t0 + u;
+                    pre[u] = (t < n) ? sd[(size_t)t * Cs] : 0.0f;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < PF; u++) {
+                int t = t0 + u;
+                pre[u] = (t < n) ? load(t) : 0.0f;
+            }
+        }
+    };
+    issue(0);
+
+    // One cascade step.  FAST = every stage is inside its steady range
+    // (4r + 3 <= m, m < n): no bounds tests, so the four float64 chains of a
+    // step are straight-line code the scheduler can interleave.
+    // Ring reads are issued one step ahead (R2 >= 2, so the slot read for step
+    // m + 1 differs from the slot written at step m): their LDS latency hides
+    // behind the arithmetic of the current step instead of stalling each stage.
+    float* rp1 = ring;
+    float* rp2 = ring + (size_t)(1 * R2) * BT;
+    float* rp3 = ring + (size_t)(2 * R2) * BT;
+    float* rp4 = ring + (size_t)(3 * R2) * BT;
+    float old1 = 0.0f, old2 = 0.0f, old3 = 0.0f, old4 = 0.0f;   // rings start zeroed
+    auto nextslot = [&](int sl) { return (sl + 1 == R2) ? 0 : sl + 1; };
+
+    auto step = [&](auto fastc, const int m, const float xin) {
+        constexpr bool FAST = decltype(fastc)::value;
+        const bool a4 = FAST || (m - 3 >= 0 && m - 3 < n + 4 * r);
+        const bool a3 = FAST || (m - 2 >= 0 && m - 2 < n + 4 * r);
+        const bool a2 = FAST || (m - 1 >= 0 && m - 1 < n + 4 * r);
+        const bool a1 = FAST || (m < n + R2);
+        const int ns1 = a1 ? nextslot(slot1) : slot1, ns2 = a2 ? nextslot(slot2) : slot2;
+        const int ns3 = a3 ? nextslot(slot3) : slot3, ns4 = a4 ? nextslot(slot4) : slot4;
+        // prefetch next step's trailing samples
+        const float nold1 = rp1[(size_t)ns1 * BT], nold2 = rp2[(size_t)ns2 * BT];
+        const float nold3 = rp3[(size_t)ns3 * BT], nold4 = rp4[(size_t)ns4 * BT];
+        // stage 4 (time t4 = m - 3): input out_3[t4], present for 2r <= t4 < n + 4r
+        if (a4) {
+            const int t = m - 3;
+            float in = (FAST || t >= R2) ? o3 : 0.0f;
+            rp4[(size_t)slot4 * BT] = in;
+            s4 += (double)in;
+            float out = (float)s4;
+            s4 -= (double)old4;
+            int i = t - 4 * r;
+            if (FAST || i >= 0) {
+                float y = DIV ? out / denom : out;
+                if (TOUT) {
+                    const int ph = i & 3;
+                    if (ph == 0) tacc0 = y;
+                    else if (ph == 1) tacc1 = y;
+                    else if (ph == 2) tacc2 = y;
+                    else *reinterpret_cast<float4*>(dst + (i - 3)) = make_float4(tacc0, tacc1, tacc2, y);
+                } else {
+                    dst[(size_t)i * Cs] = y;
+                }
+            }
+        }
+        // stage 3 (t3 = m - 2): input out_2[t3], t3 in [0, n + 4r)
+        if (a3) {
+            float in = o2;
+            rp3[(size_t)slot3 * BT] = in;
+            s3 += (double)in;
+            o3 = (float)s3;
+            s3 -= (double)old3;
+        }
+        // stage 2 (t2 = m - 1): input out_1[t2] for t2 < n + 2r, then drains to n + 4r
+        if (a2) {
+            float in = (FAST || m - 1 < n + R2) ? o1 : 0.0f;
+            rp2[(size_t)slot2 * BT] = in;
+            s2 += (double)in;
+            o2 = (float)s2;
+            s2 -= (double)old2;
+        }
+        // stage 1 (t1 = m): input data[t1] for t1 < n, drains to n + 2r
+        if (a1) {
+            float in = (FAST || m < n) ? xin : 0.0f;
+            rp1[(size_t)slot1 * BT] = in;
+            s1 += (double)in;
+            o1 = (float)s1;
+            s1 -= (double)old1;
+        }
+        // a stage that did not run keeps its pending trailing sample
+        if (a1) { old1 = nold1; slot1 = ns1; }
+        if (a2) { old2 = nold2; slot2 = ns2; }
+        if (a3) { old3 = nold3; slot3 = ns3; }
+        if (a4) { old4 = nold4; slot4 = ns4; }
+    };
+
+    for (int m0 = 0; m0 < total; m0 += PF) {
+        if (SRCMODE == 2) {
+#pragma unroll
+            for (int u = 0; u < PF; u++) {
+                bool fl = ((prew[u >> 2] >> (8 * (u & 3))) & 0xFFu) != 0;
+                cur[u] = (img == 0) ? (fl ? 0.0f : 1.0f) : (fl ? 0.0f : pre[u]);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < PF; u++) cur[u] = pre[u];
+        }
+        issue(m0 + PF);
+        if (m0 >= 4 * r + 3 && m0 + PF <= n) {
+#pragma unroll
+            for (int u = 0; u < PF; u++) step(std::true_type{}, m0 + u, cur[u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < PF; u++) step(std::false_type{}, m0 + u, cur[u]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K4b'  Single-sweep box filter (K4b) whose INPUT images are stored
+// transposed: line c is row c of an [C][ld] array (so the time-axis stage's TF
+// output feeds the frequency-axis stage without a transpose pass).  Each
+// workgroup (128 lines) stages 32 line positions at a time through an LDS
+// tile: global loads are 128-byte row segments (coalesced along the line),
+// the tile is read back column-wise, one value per thread and step.  The
+// arithmetic is that of K4b.  grid (ceil(C/128), W, 2 images), block 128,
+// dynamic LDS: 4 * 2r * 128 floats (rings) + 32 * 129 floats (tile)
+// ---------------------------------------------------------------------------
+#define CFT_BT 128
+#define CFT_PF 32
+template <bool DIV>
+__global__ void __launch_bounds__(CFT_BT)
+k_colfilter_lds_t(const float* __restrict__ srcW, const float* __restrict__ srcO,
+                  float* __restrict__ dstW, float* __restrict__ dstO,
+                  int n, int C, int ld, int r, float denom, size_t sws_img, size_t dws) {
+    extern __shared__ float cf_ring[];
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * CFT_BT;
+    const int c = c0 + tid;
+    const bool colok = c < C;
+    const size_t win = blockIdx.y;
+    const int img = blockIdx.z;
+    const int R2 = 2 * r;
+    const size_t Cs = (size_t)C;
+    const float* src = (img == 0 ? srcW : srcO) + win * sws_img;
+    float* dst = (img == 0 ? dstW : dstO) + win * dws + (colok ? c : 0);
+    float* ring = cf_ring + tid;                                 // element (p, slot) at ((p*R2)+slot)*BT
+    float* tile = cf_ring + (size_t)4 * R2 * CFT_BT;             // [CFT_PF][CFT_BT + 1]
+    for (int k = 0; k < 4 * R2; k++) ring[(size_t)k * CFT_BT] = 0.0f;
+
+    // staging: element e = j * 128 + tid of a [128 lines][32 positions] patch:
+    // line = e / 32, position = e % 32  ->  lanes 0..31 read 128 contiguous bytes
+    const int s_pos = tid & 31;
+    const int s_line0 = tid >> 5;                                // + 4 j
+    float pre[CFT_PF], cur[CFT_PF];
+    auto issue = [&](int t0) {
+#pragma unroll
+        for (int j = 0; j < CFT_PF; j++) {
+            int line = c0 + 4 * j + s_line0;
+            int t = t0 + s_pos;
+            pre[j] = (line < C && t < n) ? src[(size_t)line * ld + t] : 0.0f;
+        }
+    };
+    // registers -> LDS tile (transposed) -> this thread's 32 samples
+    auto exchange = [&]() {
+        __syncthreads();                                         // previous tile fully consumed
+#pragma unroll
+        for (int j = 0; j < CFT_PF; j++) tile[s_pos * (CFT_BT + 1) + 4 * j + s_line0] = pre[j];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < CFT_PF; u++) cur[u] = tile[u * (CFT_BT + 1) + tid];
+    };
+
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0;
+    float o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;
+    int slot1 = 0, slot2 = 0, slot3 = 0, slot4 = 0;
+    float* rp1 = ring;
+    float* rp2 = ring + (size_t)(1 * R2) * CFT_BT;
+    float* rp3 = ring + (size_t)(2 * R2) * CFT_BT;
+    float* rp4 = ring + (size_t)(3 * R2) * CFT_BT;
+    float old1 = 0.0f, old2 = 0.0f, old3 = 0.0f, old4 = 0.0f;
+    auto nextslot = [&](int sl) { return (sl + 1 == R2) ? 0 : sl + 1; };
+    const int total = n + 4 * r + 3;
+
+    auto step = [&](auto fastc, const int m, const float xin) {
+        constexpr bool FAST = decltype(fastc)::value;
+        const bool a4 = FAST || (m - 3 >= 0 && m - 3 < n + 4 * r);
+        const bool a3 = FAST || (m - 2 >= 0 && m - 2 < n + 4 * r);
+        const bool a2 = FAST || (m - 1 >= 0 && m - 1 < n + 4 * r);
+        const bool a1 = FAST || (m < n + R2);
+        const int ns1 = a1 ? nextslot(slot1) : slot1, ns2 = a2 ? nextslot(slot2) : slot2;
+        const int ns3 = a3 ? nextslot(slot3) : slot3, ns4 = a4 ? nextslot(slot4) : slot4;
+        const float nold1 = rp1[(size_t)ns1 * CFT_BT], nold2 = rp2[(size_t)ns2 * CFT_BT];
+        const float nold3 = rp3[(size_t)ns3 * CFT_BT], nold4 = rp4[(size_t)ns4 * CFT_BT];
+        if (a4) {
+            const int t = m - 3;
+            float in = (FAST || t >= R2) ? o3 : 0.0f;
+            rp4[(size_t)slot4 * CFT_BT] = in;
+            s4 += (double)in;
+            float out = (float)s4;
+            s4 -= (double)old4;
+            int i = t - 4 * r;
+            if ((FAST || i >= 0) && colok) dst[(size_t)i * Cs] = DIV ? out / denom : out;
+        }
+        if (a3) {
+            float in = o2;
+            rp3[(size_t)slot3 * CFT_BT] = in;
+            s3 += (double)in;
+            o3 = (float)s3;
+            s3 -= (double)old3;
+        }
+        if (a2) {
+            float in = (FAST || m - 1 < n + R2) ? o1 : 0.0f;
+            rp2[(size_t)slot2 * CFT_BT] = in;
+            s2 += (double)in;
+            o2 = (float)s2;
+            s2 -= (double)old2;
+        }
+        if (a1) {
+            float in = (FAST || m < n) ? xin : 0.0f;
+            rp1[(size_t)slot1 * CFT_BT] = in;
+            s1 += (double)in;
+            o1 = (float)s1;
+            s1 -= (double)old1;
+        }
+        if (a1) { old1 = nold1; slot1 = ns1; }
+        if (a2) { old2 = nold2; slot2 = ns2; }
+        if (a3) { old3 = nold3; slot3 = ns3; }
+        if (a4) { old4 = nold4; slot4 = ns4; }
+    };
+
+    issue(0);
+    for (int m0 = 0; m0 < total; m0 += CFT_PF) {
+        exchange();                 // tile of positions [m0, m0 + 32) -> cur[]
+        issue(m0 + CFT_PF);         // next tile's loads stay in flight during the arithmetic
+        if (m0 >= 4 * r + 3 && m0 + CFT_PF <= n) {
+#pragma unroll
+            for (int u = 0; u < CFT_PF; u++) step(std::true_type{}, m0 + u, cur[u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < CFT_PF; u++) step(std::false_type{}, m0 + u, cur[u]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K4c  "Lane-per-stage" form of the single-sweep box filter for medium radii
+// (the four 2r-deep delay lines of K4b no longer fit LDS at useful occupancy):
+// the four cascade stages of one line run in the four lanes of a quad, every
+// thread owning ONE stage and ONE LDS ring (2r floats), so the same LDS holds
+// four times the threads.  Stage p takes its input from lane p-1's output of
+// the previous step (DPP quad shuffle); the quad's four lanes prefetch four
+// consecutive line positions per load instruction and the stage-0 lane picks
+// them up by DPP broadcast.  Arithmetic per stage is identical to K4b (same
+// causal running sums, same order) -- only the thread that executes a stage
+// differs.  One wave (16 lines) per workgroup; no barriers.
+// grid (ceil(C/16), W, 2 images), block 64, dynamic LDS 2r * 64 floats
+// ---------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+// quad_perm(a,b,c,d): lane i of each quad reads lane {a,b,c,d}[i]
+#define QUAD_PERM(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
+
+template <int SRCMODE, bool DIV>
+__global__ void __launch_bounds__(64)
+k_colfilter_lane4(const float* __restrict__ srcW, const float* __restrict__ srcO,
+                  const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags,
+                  float* __restrict__ dstW, float* __restrict__ dstO,
+                  int n, int C, int r, float denom, size_t sws_img, size_t sws, size_t dws) {
+    extern __shared__ float cf_ring[];
+    const int lane = threadIdx.x;
+    const int p = lane & 3;                         // cascade stage of this lane
+    const int c = blockIdx.x * 16 + (lane >> 2);
+    const bool colok = c < C;
+    const int cc = colok ? c : C - 1;               // out-of-range quads compute on a valid column, store nothing
+    const size_t win = blockIdx.y;
+    const int img = blockIdx.z;
+    const int R2 = 2 * r;
+    const size_t Cs = (size_t)C;
+    const float* src = SRCMODE == 1 ? ((img == 0 ? srcW : srcO) + win * sws_img + cc) : nullptr;
+    const float* sd = SRCMODE != 1 ? srcData + win * sws + cc : nullptr;
+    const unsigned* sf4 = SRCMODE == 2 ? reinterpret_cast<const unsigned*>(srcFlags) + win * (sws / 4) + cc : nullptr;
+    float* dst = (img == 0 ? dstW : dstO) + win * dws + cc;
+    float* ring = cf_ring + lane;                   // slot k at ring[k * 64]
+    for (int k = 0; k < R2; k++) ring[k * 64] = 0.0f;
+
+    // per-stage ranges (see K4b): stage p runs for t in [0, tend); its input is
+    // the upstream value for t in [ilo, ihi), zero otherwise
+    const int tend = (p == 0) ? n + R2 : n + 4 * r;
+    const int ilo = (p == 3) ? R2 : 0;
+    const int ihi = (p == 0) ? n : ((p == 1) ? n + R2 : n + 4 * r);
+
+    constexpr int PF = 32;                          // steps per block; each lane prefetches PF/4 positions
+    float pre[PF / 4], cur[PF / 4];
+    unsigned prew[PF / 4];
+    // lane (line, p) loads positions t0 + 4 q + p
+    auto issue = [&](int t0) {
+#pragma unroll
+        for (int q = 0; q < PF / 4; q++) {
+            int t = t0 + 4 * q + p;
+            if (SRCMODE == 2) {
+                prew[q] = (t < n) ? sf4[(size_t)(t >> 2) * Cs] : 0x01010101u;
+                pre[q] = (t < n && img == 1) ? sd[(size_t)t * Cs] : 0.0f;
+            } else {
+                pre[q] = (t < n) ? src[(size_t)t * Cs] : 0.0f;
+            }
+        }
+    };
+    issue(0);
+
+    double s = 0.0;
+    float o_last = 0.0f;                            // this stage's output of the previous step
+    int slot = 0;
+    float old = 0.0f;
+    const int total = n + 4 * r + 3;
+    for (int m0 = 0; m0 < total; m0 += PF) {
+#pragma unroll
+        for (int q = 0; q < PF / 4; q++) {
+            if (SRCMODE == 2) {
+                bool fl = ((prew[q] >> (8 * p)) & 0xFFu) != 0;   // byte p of the word = position 4q + p
+                cur[q] = (img == 0) ? (fl ? 0.0f : 1.0f) : (fl ? 0.0f : pre[q]);
+            } else {
+                cur[q] = pre[q];
+            }
+        }
+        issue(m0 + PF);
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int m = m0 + u;
+            const int t = m - p;                    // this stage's time index
+            // sample for stage 0: position m was loaded by lane (u & 3) of the quad
+            float xs;
+            if ((u & 3) == 0) xs = dpp_quad<QUAD_PERM(0, 0, 0, 0)>(cur[u >> 2]);
+            else if ((u & 3) == 1) xs = dpp_quad<QUAD_PERM(1, 1, 1, 1)>(cur[u >> 2]);
+            else if ((u & 3) == 2) xs = dpp_quad<QUAD_PERM(2, 2, 2, 2)>(cur[u >> 2]);
+            else xs = dpp_quad<QUAD_PERM(3, 3, 3, 3)>(cur[u >> 2]);
+            // upstream stage's previous output
+            const float up = dpp_quad<QUAD_PERM(0, 0, 1, 2)>(o_last);
+            const bool act = t >= 0 && t < tend;
+            float in = (p == 0) ? xs : up;
+            in = (t >= ilo && t < ihi) ? in : 0.0f;
+            const int ns = (slot + 1 == R2) ? 0 : slot + 1;
+            const float nold = ring[ns * 64];       // next step's trailing sample (R2 >= 2)
+            if (act) {
+                ring[slot * 64] = in;
+                s += (double)in;
+                o_last = (float)s;
+                s -= (double)old;
+                old = nold;
+                slot = ns;
+                if (p == 3) {
+                    const int i = t - 4 * r;
+                    if (i >= 0 && colok) dst[(size_t)i * Cs] = DIV ? o_last / denom : o_last;
+                }
+            }
+        }
+    }
+}
+

@@ -1,0 +1,648 @@
+// kernels_elementwise.hpp -- amplitude / flag preconditioning, transposes, masked division, rejection, NaN interpolation, flag combination, pack / unpack, strategy steps
+// Part of the single translation unit tricolour_amd.hip (see there for the overview).
+#pragma once
+
+// ---------------------------------------------------------------------------
+// K1  _average_freq (flagging.py:819-875): |vis| -> f32, NaN -> flagged,
+// flagged -> 0, channel averaging by `factor` (f32 accumulation in ascending
+// channel order, f32 / count).  One thread per averaged sample.
+// grid (ceil(T*Fa/256), W)
+// ---------------------------------------------------------------------------
+template <int VD>
+__global__ void k_prepare(const void* __restrict__ vis, const uint8_t* __restrict__ iflags,
+                          float* __restrict__ data, uint8_t* __restrict__ flags,
+                          int T, int F, int Fa, int factor) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t NA = (size_t)T * Fa;
+    if (idx >= NA) return;
+    int t = (int)(idx / Fa), fo = (int)(idx % Fa);
+    size_t w = blockIdx.y;
+    size_t base = w * (size_t)T * F + (size_t)t * F;
+    int f0 = fo * factor;
+    int f1 = min(F, f0 + factor);
+    float sum = 0.0f;
+    int cnt = 0;
+    for (int f = f0; f < f1; f++) {
+        float a = load_amp<VD>(vis, base + f);
+        if (!iflags[base + f] && !isnan(a)) { sum += a; cnt++; }
+    }
+    size_t o = w * NA + idx;
+    if (cnt == 0) { data[o] = 0.0f; flags[o] = 1; }
+    else { data[o] = sum / (float)cnt; flags[o] = 0; }
+}
+
+__global__ void k_abs_c64(const float2* __restrict__ z, float* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = tri_hypotf(z[i].x, z[i].y);
+}
+
+// ---------------------------------------------------------------------------
+// K2  batched tiled transpose  src[W][R][C] -> dst[W][C][R]  (64x64 LDS tile)
+// grid (ceil(C/64), ceil(R/64), W), block (64,4)
+// ---------------------------------------------------------------------------
+// `denom` != 0 (float images only): the stored value is x / denom -- the
+// final division of _box_gaussian_filter1d (flagging.py:419), deferred from
+// the latency-bound sequential filter kernel to this bandwidth-bound copy.
+template <typename T>
+__global__ void k_transpose(const T* __restrict__ src, T* __restrict__ dst, int R, int C,
+                            size_t src_ws, size_t dst_ws, float denom) {
+    __shared__ T tile[64][65];
+    const T* s = src + (size_t)blockIdx.z * src_ws;
+    T* d = dst + (size_t)blockIdx.z * dst_ws;
+    int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    int tx = threadIdx.x, ty = threadIdx.y;
+    for (int j = ty; j < 64; j += 4) {
+        int r = r0 + j, c = c0 + tx;
+        if (r < R && c < C) tile[j][tx] = s[(size_t)r * C + c];
+    }
+    __syncthreads();
+    for (int j = ty; j < 64; j += 4) {
+        int c = c0 + j, r = r0 + tx;
+        if (r < R && c < C) {
+            T v = tile[tx][j];
+            if (sizeof(T) == 4 && denom != 0.0f) v = (T)((float)v / denom);
+            d[(size_t)c * R + r] = v;
+        }
+    }
+}
+
+// uint8 transpose with 4-byte accesses on both sides (R % 4 == 0, C % 4 == 0):
+// 64x64 byte tile; thread (tx, ty) of a (16,16) block moves uchar4 groups.
+__global__ void k_transpose_u8x4(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int R,
+                                 int C, size_t src_ws, size_t dst_ws) {
+    __shared__ uint8_t tile[64][68];
+    const uint8_t* s = src + (size_t)blockIdx.z * src_ws;
+    uint8_t* d = dst + (size_t)blockIdx.z * dst_ws;
+    int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    int tx = threadIdx.x, ty = threadIdx.y;   // 16 x 16
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int r = r0 + ty + 16 * j, c = c0 + 4 * tx;
+        uchar4 v = make_uchar4(0, 0, 0, 0);
+        if (r < R && c < C) v = *reinterpret_cast<const uchar4*>(s + (size_t)r * C + c);
+        *reinterpret_cast<uchar4*>(&tile[ty + 16 * j][4 * tx]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int c = c0 + ty + 16 * j, r = r0 + 4 * tx;   // output row = source column
+        if (c < C && r < R) {
+            int cc = ty + 16 * j;
+            uchar4 v = make_uchar4(tile[4 * tx][cc], tile[4 * tx + 1][cc], tile[4 * tx + 2][cc], tile[4 * tx + 3][cc]);
+            *reinterpret_cast<uchar4*>(d + (size_t)c * R + r) = v;
+        }
+    }
+}
+
+// r == 0 on both axes: weight = !flag, data = flag ? 0 : x (flagging.py:500-503
+// followed by the plain copy of flagging.py:465-466).
+__global__ void k_build_wo(const float* __restrict__ data, const uint8_t* __restrict__ flags,
+                           float* __restrict__ w, float* __restrict__ o, size_t nper,
+                           size_t sws, size_t dws) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nper) return;
+    size_t win = blockIdx.y;
+    bool fl = flags[win * sws + i] != 0;
+    w[win * dws + i] = fl ? 0.0f : 1.0f;
+    o[win * dws + i] = fl ? 0.0f : data[win * sws + i];
+}
+
+__global__ void k_build_wo4(const float* __restrict__ data, const uint8_t* __restrict__ flags,
+                            float* __restrict__ w, float* __restrict__ o, size_t n4per,
+                            size_t sws, size_t dws) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4per) return;
+    size_t win = blockIdx.y;
+    uchar4 f = reinterpret_cast<const uchar4*>(flags + win * sws)[i];
+    float4 d = reinterpret_cast<const float4*>(data + win * sws)[i];
+    reinterpret_cast<float4*>(w + win * dws)[i] =
+        make_float4(f.x ? 0.0f : 1.0f, f.y ? 0.0f : 1.0f, f.z ? 0.0f : 1.0f, f.w ? 0.0f : 1.0f);
+    reinterpret_cast<float4*>(o + win * dws)[i] =
+        make_float4(f.x ? 0.0f : d.x, f.y ? 0.0f : d.y, f.z ? 0.0f : d.z, f.w ? 0.0f : d.w);
+}
+
+// ---------------------------------------------------------------------------
+// K5  masked_gaussian_filter tail (flagging.py:506-513) and the background
+// residual (flagging.py:563-566):  bg = w == 0 ? NaN : o / w;
+//   MODE 0: o <- bg          MODE 1: o <- |data - bg|
+// ---------------------------------------------------------------------------
+template <int MODE>
+__global__ void k_masked_div(const float* __restrict__ w, float* __restrict__ o,
+                             const float* __restrict__ data, size_t nper, size_t ws_wo,
+                             size_t ws_data, float denom, uint8_t* __restrict__ nanflag, int C) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nper) return;
+    size_t win = blockIdx.y;
+    float wv = w[win * ws_wo + i];
+    float ov = o[win * ws_wo + i];
+    if (denom != 0.0f) { wv = wv / denom; ov = ov / denom; }   // deferred flagging.py:419
+    float bg = (wv == 0.0f) ? NAN : ov / wv;
+    // remember which lines (columns) hold a NaN: only those need the
+    // sequential interpolation pass
+    if (MODE == 0 && nanflag && isnan(bg)) nanflag[win * (size_t)C + (i % C)] = 1;
+    if (MODE == 1) bg = fabsf(data[win * ws_data + i] - bg);
+    o[win * ws_wo + i] = bg;
+}
+
+// flags |= resid > median * (MAD_NORMAL * reject)   (flagging.py:567-574);
+// float32 residual compared in float64; NaN compares false.
+// Array layout [L][C] per window; chunk_of[l] gives the chunk of line index l.
+// thr index: TWOD ? (win*G + g) : (c*G + g)   [spectrum layout: column = window]
+template <bool TWOD>
+__global__ void k_reject(const float* __restrict__ resid, uint8_t* __restrict__ flags,
+                         const double* __restrict__ med, const int* __restrict__ chunk_of,
+                         double scale, int L, int C, int G, size_t ws_resid, size_t ws_flags) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)L * C) return;
+    size_t win = blockIdx.y;
+    int l = (int)(i / C), c = (int)(i % C);
+    int g = chunk_of[l];
+    double m = TWOD ? med[win * G + g] : med[(size_t)c * G + g];
+    double thr = m * scale;
+    if ((double)resid[win * ws_resid + i] > thr) flags[win * ws_flags + i] = 1;
+}
+
+// ---------------------------------------------------------------------------
+// K6  _linearly_interpolate_nans1d (flagging.py:307-344) along the line axis
+// of [L][C], one thread per column.  numba typing: grad = (f32 - f32) / int64
+// -> float64; value = f32(f32 + int64 * f64) evaluated in float64.
+// grid (ceil(C/256), W)
+// ---------------------------------------------------------------------------
+__global__ void k_colinterp(float* __restrict__ a, int L, int C, size_t ws,
+                            const uint8_t* __restrict__ nanflag) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (nanflag && !nanflag[(size_t)blockIdx.y * C + c]) return;   // no NaN in this line
+    float* x = a + (size_t)blockIdx.y * ws + c;
+    const size_t Cs = (size_t)C;
+    int last = -1;       // index of the last valid sample
+    float lastv = 0.0f;
+    int run = 0;         // start of the current NaN run
+    for (int i = 0; i < L; i++) {
+        float v = x[(size_t)i * Cs];
+        if (isnan(v)) continue;
+        if (run < i) {
+            if (last < 0) {
+                for (int j = run; j < i; j++) x[(size_t)j * Cs] = v;  // extrapolate backwards
+            } else {
+                float diff = v - lastv;
+                double grad = (double)diff / (double)(i - last);
+                for (int j = run; j < i; j++)
+                    x[(size_t)j * Cs] = (float)((double)lastv + (double)(j - last) * grad);
+            }
+        }
+        last = i;
+        lastv = v;
+        run = i + 1;
+    }
+    if (run < L) {
+        float fill = last < 0 ? 0.0f : lastv;  // all NaN -> zeros; else extrapolate forwards
+        for (int j = run; j < L; j++) x[(size_t)j * Cs] = fill;
+    }
+}
+
+// out = a - b  (flagging.py:950, 962)
+__global__ void k_sub(const float* __restrict__ a, const float* __restrict__ b,
+                      float* __restrict__ out, size_t nper, size_t ws_a, size_t ws_b,
+                      size_t ws_o) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nper) return;
+    size_t win = blockIdx.y;
+    out[win * ws_o + i] = a[win * ws_a + i] - b[win * ws_b + i];
+}
+
+__global__ void k_or(uint8_t* __restrict__ a, const uint8_t* __restrict__ b, size_t nper,
+                     size_t ws_a, size_t ws_b) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nper) return;
+    size_t win = blockIdx.y;
+    if (b[win * ws_b + i]) a[win * ws_a + i] = 1;
+}
+
+__global__ void k_copy_u8(const uint8_t* __restrict__ a, uint8_t* __restrict__ b, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) b[i] = a[i];
+}
+
+// flags[w][t][f] |= spec[f][w]   (flagging.py:954); spec in spectrum layout
+__global__ void k_or_spec(uint8_t* __restrict__ flags, const uint8_t* __restrict__ spec, int T,
+                          int Fa, int Wn) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)T * Fa) return;
+    size_t win = blockIdx.y;
+    int f = (int)(i % Fa);
+    if (spec[(size_t)f * Wn + win]) flags[win * (size_t)T * Fa + i] = 1;
+}
+
+// ---------------------------------------------------------------------------
+// K8  _combine_flags + _unaverage_freq (flagging.py:784-918), TF layout.
+// comb[t][fa] = any over t' in [t - e/2, t - e/2 + e) of (spec|time|freq).
+// ---------------------------------------------------------------------------
+__global__ void k_combine(const uint8_t* __restrict__ spec, const uint8_t* __restrict__ tflags,
+                          const uint8_t* __restrict__ fflags, uint8_t* __restrict__ comb, int T,
+                          int Fa, int Wn, int lo, int hi) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)T * Fa) return;
+    size_t win = blockIdx.y;
+    int t = (int)(i / Fa), f = (int)(i % Fa);
+    size_t base = win * (size_t)T * Fa;
+    int t0 = max(t + lo, 0), t1 = min(t + hi, T);
+    uint8_t v = 0;
+    if (t1 > t0) {
+        if (spec[(size_t)f * Wn + win]) v = 1;
+        for (int tt = t0; tt < t1 && !v; tt++) {
+            size_t a = base + (size_t)tt * Fa + f;
+            v = (tflags[a] | fflags[a]) ? 1 : 0;
+        }
+    }
+    comb[base + i] = v;
+}
+
+// dil[t][f] = any comb[t][f'/avg] for f' in [f - e/2, f - e/2 + e) clamped;
+// per-row and per-column counts of dil (flagging.py:896-908).
+// grid (ceil(F/256), T, W), block 256
+__global__ void k_unaverage(const uint8_t* __restrict__ comb, uint8_t* __restrict__ dil,
+                            int* __restrict__ rowcnt, int* __restrict__ colcnt, int T, int Fa,
+                            int F, int avg, int lo, int hi) {
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    int t = blockIdx.y;
+    size_t win = blockIdx.z;
+    int v = 0;
+    if (f < F) {
+        int f0 = max(f + lo, 0), f1 = min(f + hi, F);
+        const uint8_t* row = comb + win * (size_t)T * Fa + (size_t)t * Fa;
+        for (int ff = f0; ff < f1 && !v; ff++) v = row[ff / avg] ? 1 : 0;
+        dil[win * (size_t)T * F + (size_t)t * F + f] = (uint8_t)v;
+        if (v) atomicAdd(&colcnt[win * (size_t)F + f], 1);
+    }
+    // row count: wave ballot + one atomic per wave
+    unsigned long long b = __ballot(v);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&rowcnt[win * (size_t)T + t], __popcll(b));
+}
+
+// out = dil | row rule | column rule | isnan(vis); iter |= out
+// (flagging.py:910-918, 777-781, 1193)
+template <int VD>
+__global__ void k_final(const uint8_t* __restrict__ dil, const int* __restrict__ rowcnt,
+                        const int* __restrict__ colcnt, const void* __restrict__ vis,
+                        uint8_t* __restrict__ out, uint8_t* __restrict__ iter, int T, int F,
+                        double row_limit, double col_limit, int update_iter) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)T * F) return;
+    size_t win = blockIdx.y;
+    int t = (int)(i / F), f = (int)(i % F);
+    size_t a = win * (size_t)T * F + i;
+    bool v = dil[a] != 0;
+    v = v || ((double)rowcnt[win * (size_t)T + t] > row_limit);
+    v = v || ((double)colcnt[win * (size_t)F + f] > col_limit);
+    v = v || load_isnan<VD>(vis, a);
+    out[a] = v ? 1 : 0;
+    if (update_iter && v) iter[a] = 1;
+}
+
+// ---------------------------------------------------------------------------
+// Vectorised (16 bytes of flags / 4 floats per thread) forms of the
+// elementwise kernels above, used when the row lengths are multiples of 16
+// (every production shape); the scalar kernels remain the general fallback.
+// Flags are 0/1 bytes, so byte-wise OR is a plain bitwise OR of the words.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint4 or4(uint4 a, uint4 b) { return make_uint4(a.x | b.x, a.y | b.y, a.z | b.z, a.w | b.w); }
+// per byte: x != 0 ? 1 : 0 (no cross-byte carries)
+__device__ __forceinline__ unsigned nz_bytes(unsigned x) {
+    unsigned t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    return ((t | x) & 0x80808080u) >> 7;
+}
+
+template <int VD>
+__global__ void k_prepare4(const void* __restrict__ vis, const uint8_t* __restrict__ iflags,
+                           float* __restrict__ data, uint8_t* __restrict__ flags, size_t n4) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // group of 4 samples, flat over the batch
+    if (i >= n4) return;
+    uchar4 f = reinterpret_cast<const uchar4*>(iflags)[i];
+    float a[4];
+    if (VD == TRI_VIS_C64) {
+        float4 z0 = reinterpret_cast<const float4*>(vis)[2 * i];
+        float4 z1 = reinterpret_cast<const float4*>(vis)[2 * i + 1];
+        a[0] = tri_hypotf(z0.x, z0.y); a[1] = tri_hypotf(z0.z, z0.w);
+        a[2] = tri_hypotf(z1.x, z1.y); a[3] = tri_hypotf(z1.z, z1.w);
+    } else {
+        float4 z = reinterpret_cast<const float4*>(vis)[i];
+        a[0] = fabsf(z.x); a[1] = fabsf(z.y); a[2] = fabsf(z.z); a[3] = fabsf(z.w);
+    }
+    unsigned char fl[4] = {f.x, f.y, f.z, f.w};
+    float o[4];
+    unsigned char of[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        bool bad = fl[k] != 0 || isnan(a[k]);
+        // factor 1: sum = 0 + a, count 1, a / 1.0f = a (flagging.py:858-870)
+        o[k] = bad ? 0.0f : (0.0f + a[k]) / 1.0f;
+        of[k] = bad ? 1 : 0;
+    }
+    reinterpret_cast<float4*>(data)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    reinterpret_cast<uchar4*>(flags)[i] = make_uchar4(of[0], of[1], of[2], of[3]);
+}
+
+// OP 0: b = a   OP 1: b |= a   OP 2: b = (a != 0)     (16 bytes per thread)
+template <int OP>
+__global__ void k_u8_op16(const uint8_t* __restrict__ a, uint8_t* __restrict__ b, size_t n16per,
+                          size_t ws_a, size_t ws_b) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n16per) return;
+    size_t win = blockIdx.y;
+    uint4 va = reinterpret_cast<const uint4*>(a + win * ws_a)[i];
+    uint4* pb = reinterpret_cast<uint4*>(b + win * ws_b) + i;
+    if (OP == 0) *pb = va;
+    else if (OP == 1) *pb = or4(*pb, va);
+    else *pb = make_uint4(nz_bytes(va.x), nz_bytes(va.y), nz_bytes(va.z), nz_bytes(va.w));
+}
+
+// spectrum flags [Fa][Wn] -> rows [Wn][Fa] (tiny), so that the per-window
+// kernels below can read 16 channels at a time
+__global__ void k_spec_rows(const uint8_t* __restrict__ spec, uint8_t* __restrict__ rows, int Fa, int Wn) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)Fa * Wn) return;
+    int w = (int)(i / Fa), f = (int)(i % Fa);
+    rows[i] = spec[(size_t)f * Wn + w];
+}
+
+// flags[w][t][f..f+15] |= spec_rows[w][f..f+15]
+__global__ void k_or_spec16(uint8_t* __restrict__ flags, const uint8_t* __restrict__ spec_rows, int T, int Fa16) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)T * Fa16) return;
+    size_t win = blockIdx.y;
+    int f16 = (int)(i % Fa16);
+    uint4 sp = reinterpret_cast<const uint4*>(spec_rows + win * (size_t)Fa16 * 16)[f16];
+    uint4* pf = reinterpret_cast<uint4*>(flags + win * (size_t)T * Fa16 * 16) + i;
+    *pf = or4(*pf, sp);
+}
+
+// _combine_flags (flagging.py:784-816), 16 channels per thread
+__global__ void k_combine16(const uint8_t* __restrict__ spec_rows, const uint8_t* __restrict__ tflags,
+                            const uint8_t* __restrict__ fflags, uint8_t* __restrict__ comb, int T,
+                            int Fa16, int lo, int hi) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)T * Fa16) return;
+    size_t win = blockIdx.y;
+    int t = (int)(i / Fa16), f16 = (int)(i % Fa16);
+    size_t base = win * (size_t)T * Fa16;
+    int t0 = max(t + lo, 0), t1 = min(t + hi, T);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (t1 > t0) {
+        v = reinterpret_cast<const uint4*>(spec_rows + win * (size_t)Fa16 * 16)[f16];
+        const uint4* tp = reinterpret_cast<const uint4*>(tflags) + base;
+        const uint4* fp = reinterpret_cast<const uint4*>(fflags) + base;
+        for (int tt = t0; tt < t1; tt++) {
+            size_t a = (size_t)tt * Fa16 + f16;
+            v = or4(v, or4(tp[a], fp[a]));
+        }
+    }
+    reinterpret_cast<uint4*>(comb)[base + i] = v;
+}
+
+// _unaverage_freq (flagging.py:896-908) for average_freq == 1, frequency
+// dilation over [f + LO, f + LO + E), 16 channels per thread; row counts by
+// popcount + one atomic per wave; column counts by k_colcount.
+// grid (ceil(F16/64), T, W), block 64
+template <int LO, int E>
+__global__ void k_unaverage16(const uint8_t* __restrict__ comb, uint8_t* __restrict__ dil,
+                              int* __restrict__ rowcnt, int T, int F16) {
+    int f16 = blockIdx.x * blockDim.x + threadIdx.x;
+    int t = blockIdx.y;
+    size_t win = blockIdx.z;
+    int cnt = 0;
+    if (f16 < F16) {
+        const uint4* row = reinterpret_cast<const uint4*>(comb) + (win * (size_t)T + t) * F16;
+        uint4 z = make_uint4(0, 0, 0, 0);
+        uint4 p = f16 > 0 ? row[f16 - 1] : z;
+        uint4 c = row[f16];
+        uint4 n = f16 + 1 < F16 ? row[f16 + 1] : z;
+        unsigned w[12] = {p.x, p.y, p.z, p.w, c.x, c.y, c.z, c.w, n.x, n.y, n.z, n.w};
+        unsigned o[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            unsigned v = 0;
+#pragma unroll
+            for (int sft = LO; sft < LO + E; sft++) {
+                const int idx = 16 + k + sft;   // byte index into the 48-byte window
+                v |= (w[idx >> 2] >> (8 * (idx & 3))) & 0xFFu;
+            }
+            o[k >> 2] |= (v & 1u) << (8 * (k & 3));
+        }
+        reinterpret_cast<uint4*>(dil)[(win * (size_t)T + t) * F16 + f16] = make_uint4(o[0], o[1], o[2], o[3]);
+        cnt = __popc(o[0]) + __popc(o[1]) + __popc(o[2]) + __popc(o[3]);
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&rowcnt[win * (size_t)T + t], cnt);
+}
+
+// column counts of a [T][F] 0/1 byte image: one thread per 4 columns
+// grid (ceil(F4/256), W)
+__global__ void k_colcount(const uint8_t* __restrict__ dil, int* __restrict__ colcnt, int T, int F4) {
+    int f4 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f4 >= F4) return;
+    size_t win = blockIdx.y;
+    const unsigned* p = reinterpret_cast<const unsigned*>(dil) + win * (size_t)T * F4 + f4;
+    unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    int t = 0;
+    for (; t + 8 <= T; t += 8) {
+        unsigned v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = p[(size_t)(t + u) * F4];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            c0 += v[u] & 0xFFu; c1 += (v[u] >> 8) & 0xFFu; c2 += (v[u] >> 16) & 0xFFu; c3 += v[u] >> 24;
+        }
+    }
+    for (; t < T; t++) {
+        unsigned v = p[(size_t)t * F4];
+        c0 += v & 0xFFu; c1 += (v >> 8) & 0xFFu; c2 += (v >> 16) & 0xFFu; c3 += v >> 24;
+    }
+    reinterpret_cast<int4*>(colcnt)[win * (size_t)F4 + f4] = make_int4((int)c0, (int)c1, (int)c2, (int)c3);
+}
+
+// k_final, 16 samples per thread
+template <int VD>
+__global__ void k_final16(const uint8_t* __restrict__ dil, const int* __restrict__ rowcnt,
+                          const int* __restrict__ colcnt, const void* __restrict__ vis,
+                          uint8_t* __restrict__ out, uint8_t* __restrict__ iter, int T, int F16,
+                          double row_limit, double col_limit, int update_iter) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)T * F16) return;
+    size_t win = blockIdx.y;
+    int t = (int)(i / F16), f16 = (int)(i % F16);
+    size_t a16 = win * (size_t)T * F16 + i;
+    uint4 d = reinterpret_cast<const uint4*>(dil)[a16];
+    unsigned dw[4] = {d.x, d.y, d.z, d.w};
+    bool rowall = (double)rowcnt[win * (size_t)T + t] > row_limit;
+    const int4* cc = reinterpret_cast<const int4*>(colcnt + win * (size_t)F16 * 16) + (size_t)f16 * 4;
+    unsigned o[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        int4 c4 = cc[q];
+        int cv[4] = {c4.x, c4.y, c4.z, c4.w};
+        unsigned nanb = 0;
+        if (VD == TRI_VIS_C64) {
+            const float4* vp = reinterpret_cast<const float4*>(vis) + (a16 * 16 + q * 4) / 2;
+            float4 z0 = vp[0], z1 = vp[1];
+            nanb = ((isnan(z0.x) || isnan(z0.y)) ? 1u : 0u) | ((isnan(z0.z) || isnan(z0.w)) ? 0x100u : 0u) |
+                   ((isnan(z1.x) || isnan(z1.y)) ? 0x10000u : 0u) | ((isnan(z1.z) || isnan(z1.w)) ? 0x1000000u : 0u);
+        } else {
+            float4 z = reinterpret_cast<const float4*>(vis)[(a16 * 16 + q * 4) / 4];
+            nanb = (isnan(z.x) ? 1u : 0u) | (isnan(z.y) ? 0x100u : 0u) | (isnan(z.z) ? 0x10000u : 0u) |
+                   (isnan(z.w) ? 0x1000000u : 0u);
+        }
+        unsigned colb = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) colb |= ((double)cv[k] > col_limit ? 1u : 0u) << (8 * k);
+        o[q] = rowall ? 0x01010101u : (dw[q] | colb | nanb);
+    }
+    uint4 ov = make_uint4(o[0], o[1], o[2], o[3]);
+    reinterpret_cast<uint4*>(out)[a16] = ov;
+    if (update_iter) {
+        uint4* ip = reinterpret_cast<uint4*>(iter) + a16;
+        *ip = or4(*ip, ov);
+    }
+}
+
+template <int MODE>
+__global__ void k_masked_div4(const float* __restrict__ w, float* __restrict__ o,
+                              const float* __restrict__ data, size_t n4per, size_t ws_wo, size_t ws_data,
+                              float denom, uint8_t* __restrict__ nanflag, int C) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4per) return;
+    size_t win = blockIdx.y;
+    float4 wv = reinterpret_cast<const float4*>(w + win * ws_wo)[i];
+    float4* po = reinterpret_cast<float4*>(o + win * ws_wo) + i;
+    float4 ov = *po;
+    if (denom != 0.0f) {   // deferred flagging.py:419
+        wv = make_float4(wv.x / denom, wv.y / denom, wv.z / denom, wv.w / denom);
+        ov = make_float4(ov.x / denom, ov.y / denom, ov.z / denom, ov.w / denom);
+    }
+    float bg[4] = {(wv.x == 0.0f) ? NAN : ov.x / wv.x, (wv.y == 0.0f) ? NAN : ov.y / wv.y,
+                   (wv.z == 0.0f) ? NAN : ov.z / wv.z, (wv.w == 0.0f) ? NAN : ov.w / wv.w};
+    if (MODE == 0 && nanflag) {
+        int cb = (int)((i * 4) % C);   // C % 4 == 0: the four samples are columns cb .. cb + 3
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (isnan(bg[k])) nanflag[win * (size_t)C + cb + k] = 1;
+    }
+    if (MODE == 1) {
+        float4 dv = reinterpret_cast<const float4*>(data + win * ws_data)[i];
+        bg[0] = fabsf(dv.x - bg[0]); bg[1] = fabsf(dv.y - bg[1]);
+        bg[2] = fabsf(dv.z - bg[2]); bg[3] = fabsf(dv.w - bg[3]);
+    }
+    *po = make_float4(bg[0], bg[1], bg[2], bg[3]);
+}
+
+__global__ void k_sub4(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                       size_t n4per, size_t ws_a, size_t ws_b, size_t ws_o) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4per) return;
+    size_t win = blockIdx.y;
+    float4 x = reinterpret_cast<const float4*>(a + win * ws_a)[i];
+    float4 y = reinterpret_cast<const float4*>(b + win * ws_b)[i];
+    reinterpret_cast<float4*>(out + win * ws_o)[i] = make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w);
+}
+
+// k_reject<true>, 4 samples per thread (C % 4 == 0 keeps a group in one line)
+__global__ void k_reject4(const float* __restrict__ resid, uint8_t* __restrict__ flags,
+                          const double* __restrict__ med, const int* __restrict__ chunk_of,
+                          double scale, int C4, int G, size_t n4per, size_t ws_resid, size_t ws_flags) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4per) return;
+    size_t win = blockIdx.y;
+    int l = (int)(i / C4);
+    double thr = med[win * G + chunk_of[l]] * scale;
+    float4 rv = reinterpret_cast<const float4*>(resid + win * ws_resid)[i];
+    uchar4* pf = reinterpret_cast<uchar4*>(flags + win * ws_flags) + i;
+    uchar4 f = *pf;
+    if ((double)rv.x > thr) f.x = 1;
+    if ((double)rv.y > thr) f.y = 1;
+    if ((double)rv.z > thr) f.z = 1;
+    if ((double)rv.w > thr) f.w = 1;
+    *pf = f;
+}
+
+// ---------------------------------------------------------------------------
+// pack / unpack (packing.py:243-278, 369-415) with a precomputed row map
+// ---------------------------------------------------------------------------
+__global__ void k_fill_windows(float2* __restrict__ vis, uint8_t* __restrict__ flags, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    vis[i] = make_float2(NAN, NAN);
+    flags[i] = 1;
+}
+
+// one thread per (row, chan); loops over corr. grid (ceil(nchan/256), rows)
+__global__ void k_pack(const float2* __restrict__ data, const uint8_t* __restrict__ flag,
+                       const int32_t* __restrict__ row_bl, const int32_t* __restrict__ row_time,
+                       int nchan, int ncorr, int nbl, int ntime, float2* __restrict__ vw,
+                       uint8_t* __restrict__ fw) {
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    size_t r = blockIdx.y;
+    if (f >= nchan) return;
+    int bl = row_bl[r], t = row_time[r];
+    if (bl < 0 || bl >= nbl || t < 0 || t >= ntime) return;
+    for (int c = 0; c < ncorr; c++) {
+        size_t i = (r * nchan + f) * (size_t)ncorr + c;
+        size_t o = (((size_t)bl * ncorr + c) * ntime + t) * (size_t)nchan + f;
+        vw[o] = data[i];
+        fw[o] = flag[i];
+    }
+}
+
+__global__ void k_unpack(const uint8_t* __restrict__ fw, const int32_t* __restrict__ row_bl,
+                         const int32_t* __restrict__ row_time, int nchan, int ncorr, int nbl,
+                         int ntime, uint8_t* __restrict__ out) {
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    size_t r = blockIdx.y;
+    if (f >= nchan) return;
+    int bl = row_bl[r], t = row_time[r];
+    bool ok = !(bl < 0 || bl >= nbl || t < 0 || t >= ntime);
+    for (int c = 0; c < ncorr; c++) {
+        size_t i = (r * nchan + f) * (size_t)ncorr + c;
+        out[i] = ok ? fw[(((size_t)bl * ncorr + c) * ntime + t) * (size_t)nchan + f] : 0;
+    }
+}
+
+// ===========================================================================
+// "Next" rows: the cheap strategy steps that surround
+// sum_threshold in conf/default.yaml, so a whole strategy chain can stay
+// device-resident.
+// ===========================================================================
+// flag_nans_and_zeros (flagging.py:29-62): out = vis == 0 | isnan(vis) | flags != 0
+template <int VD>
+__global__ void k_flag_nans_zeros(const void* __restrict__ vis, const uint8_t* __restrict__ flags,
+                                  uint8_t* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool f;
+    if (VD == TRI_VIS_C64) {
+        float2 z = reinterpret_cast<const float2*>(vis)[i];
+        f = (z.x == 0.0f && z.y == 0.0f) || isnan(z.x) || isnan(z.y);
+    } else {
+        float x = reinterpret_cast<const float*>(vis)[i];
+        f = x == 0.0f || isnan(x);
+    }
+    out[i] = (f || flags[i] != 0) ? 1 : 0;
+}
+
+// out = flags, then for every selected baseline: out |= chan_mask (mode 0) or
+// out = chan_mask (mode 1), broadcast over corr and time.  Serves
+// apply_static_mask (flagging.py:151-172, one call per mask) and flag_autos
+// (flagging.py:90-93: all-ones mask on the auto-correlation baselines).
+// In-place safe (out == flags).  grid (ceil(nchan/256), ncorr*ntime, nbl)
+__global__ void k_apply_bl_chan_mask(const uint8_t* __restrict__ flags, uint8_t* __restrict__ out,
+                                     const uint8_t* __restrict__ bl_sel,
+                                     const uint8_t* __restrict__ chan_mask, int mode, int nchan,
+                                     size_t rows_per_bl) {
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nchan) return;
+    size_t bl = blockIdx.z;
+    size_t a = (bl * rows_per_bl + blockIdx.y) * (size_t)nchan + f;
+    uint8_t v = flags[a];
+    if (bl_sel[bl]) v = mode == 0 ? (uint8_t)((v | chan_mask[f]) ? 1 : 0) : (uint8_t)(chan_mask[f] ? 1 : 0);
+    out[a] = v;
+}
+

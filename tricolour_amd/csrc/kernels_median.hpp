@@ -1,0 +1,340 @@
+// kernels_median.hpp -- exact segmented medians (radix select on the |x| bit pattern)
+// Part of the single translation unit tricolour_amd.hip (see there for the overview).
+#pragma once
+
+// ---------------------------------------------------------------------------
+// K3  segmented exact median of |x| over unflagged samples ("row select").
+// np.median under numba (np/arraymath.py:1365-1399): odd n -> middle element,
+// even n -> f32(a + b) / 2 in float64.  NaN when nothing is unflagged
+// (flagging.py:276-277, 300-301).  |x| of a float32 is a sign-bit clear, so
+// ordering |x| = ordering the low 31 bits as unsigned integers: a 4-digit
+// (7+8+8+8 bit) radix select is exact.
+// One workgroup per segment.  Segment (win, row, g) covers elements
+//   data[win*WSd + row*RS + (seg_start[g] + i)*ES],  i < seg_len[g]
+// (flags likewise with window stride WSf).
+// Output med[(win*R + row)*G + g] (float64).
+// grid (R*G, W), block 256
+// ---------------------------------------------------------------------------
+#define SEL_CACHE 8
+#define SEL_BINS 2048
+// Three radix passes over the 31-bit key: digits of 11, 10 and 10 bits.  The
+// even-count partner (rank n/2 - 1) needs no extra pass: it equals the median
+// key when that key is duplicated below rank n/2, else the largest occupied
+// bin below it in the last histogram, else the largest key with a smaller
+// 21-bit prefix (tracked during the last pass).
+// VEC: segments are contiguous, 16-byte aligned and a multiple of 4 long ->
+// float4 / uchar4 loads.
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+k_median(const float* __restrict__ data, const uint8_t* __restrict__ flags,
+         double* __restrict__ med, size_t WSd, size_t WSf, size_t RS, size_t ES,
+         const int64_t* __restrict__ seg_start, const int64_t* __restrict__ seg_len,
+         int R, int G) {
+    __shared__ unsigned hist[SEL_BINS];
+    __shared__ unsigned sh_wsum[4];
+    __shared__ unsigned sh_prefix, sh_k, sh_sel, sh_maxbelow, sh_lobin1;
+    const unsigned SENT = 0xFFFFFFFFu;
+    int seg = blockIdx.x;
+    int row = seg / G, g = seg % G;
+    size_t win = blockIdx.y;
+    int64_t len = seg_len[g];
+    size_t rel = (size_t)row * RS + (size_t)seg_start[g] * ES;
+    data += win * WSd + rel;
+    flags += win * WSf + rel;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool cached = !VEC && len <= (int64_t)SEL_CACHE * 256;
+    unsigned keys[SEL_CACHE];
+    if (cached) {
+#pragma unroll
+        for (int u = 0; u < SEL_CACHE; u++) {
+            int64_t i = (int64_t)u * 256 + tid;
+            unsigned k = SENT;
+            if (i < len) {
+                size_t a = (size_t)i * ES;
+                if (!flags[a]) k = __float_as_uint(data[a]) & 0x7FFFFFFFu;
+            }
+            keys[u] = k;
+        }
+    }
+    if (tid == 0) { sh_maxbelow = 0; sh_lobin1 = 0; }
+    unsigned prefix = 0, pmask = 0, kk = 0, n = 0;
+    for (int p = 0; p < 3; p++) {
+        const int shift = p == 0 ? 20 : (p == 1 ? 10 : 0);
+        const unsigned dm = p == 0 ? 0x7FFu : 0x3FFu;
+#pragma unroll
+        for (int u = 0; u < SEL_BINS / 256; u++) hist[u * 256 + tid] = 0;
+        __syncthreads();
+        unsigned mb = 0;
+        auto visit = [&](unsigned k) {
+            if ((k & pmask) == prefix) atomicAdd(&hist[(k >> shift) & dm], 1u);
+            else if (p == 2 && k < prefix) mb = max(mb, k);
+        };
+        if (cached) {
+#pragma unroll
+            for (int u = 0; u < SEL_CACHE; u++)
+                if (keys[u] != SENT) visit(keys[u]);
+        } else if (VEC) {
+            const float4* d4 = reinterpret_cast<const float4*>(data);
+            const uchar4* f4 = reinterpret_cast<const uchar4*>(flags);
+            for (int64_t i = tid; i < len / 4; i += 256) {
+                float4 dv = d4[i];
+                uchar4 fv = f4[i];
+                if (!fv.x) visit(__float_as_uint(dv.x) & 0x7FFFFFFFu);
+                if (!fv.y) visit(__float_as_uint(dv.y) & 0x7FFFFFFFu);
+                if (!fv.z) visit(__float_as_uint(dv.z) & 0x7FFFFFFFu);
+                if (!fv.w) visit(__float_as_uint(dv.w) & 0x7FFFFFFFu);
+            }
+        } else {
+            for (int64_t i = tid; i < len; i += 256) {
+                size_t a = (size_t)i * ES;
+                if (!flags[a]) visit(__float_as_uint(data[a]) & 0x7FFFFFFFu);
+            }
+        }
+        if (p == 2 && mb) atomicMax(&sh_maxbelow, mb);
+        __syncthreads();
+        // bucket search: thread t owns bins [8t, 8t+8)
+        unsigned v[8];
+        {
+            uint4 q0 = reinterpret_cast<const uint4*>(hist)[2 * tid];
+            uint4 q1 = reinterpret_cast<const uint4*>(hist)[2 * tid + 1];
+            v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w;
+            v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+        }
+        unsigned sacc = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) sacc += v[j];
+        unsigned inc = sacc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            unsigned t2 = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t2;
+        }
+        if (lane == 63) sh_wsum[wave] = inc;
+        __syncthreads();
+        unsigned woff = 0, total = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; w2++) {
+            unsigned t2 = sh_wsum[w2];
+            if (w2 < wave) woff += t2;
+            total += t2;
+        }
+        if (p == 0) { n = total; kk = total >> 1; }
+        unsigned exc = woff + inc - sacc;
+        if (total > 0 && kk >= exc && kk < exc + sacc) {
+            unsigned c = exc;
+            int j = 0;
+#pragma unroll
+            for (int q = 0; q < 7; q++)
+                if (j == q && kk >= c + v[q]) { c += v[q]; j = q + 1; }
+            sh_sel = 8u * tid + j;
+            sh_prefix = prefix | ((8u * tid + j) << shift);
+            sh_k = kk - c;
+        }
+        __syncthreads();
+        if (n == 0) break;
+        if (p == 2) {
+            unsigned sel = sh_sel, cand = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (v[j] && 8u * tid + j < sel) cand = 8u * tid + j + 1;
+            if (cand) atomicMax(&sh_lobin1, cand);
+        }
+        prefix = sh_prefix;
+        kk = sh_k;
+        pmask |= dm << shift;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        size_t oidx = (win * (size_t)R + row) * G + g;
+        double m;
+        if (n == 0) m = __longlong_as_double(0x7FF8000000000000LL);
+        else if (n & 1u) m = (double)__uint_as_float(prefix);
+        else {
+            unsigned hi = prefix, lo;
+            if (kk > 0) lo = hi;
+            else if (sh_lobin1) lo = (hi & ~0x3FFu) | (sh_lobin1 - 1);
+            else lo = sh_maxbelow;
+            float sm = __uint_as_float(lo) + __uint_as_float(hi);
+            m = (double)sm / 2.0;
+        }
+        med[oidx] = m;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K3b  Wave-per-segment form of k_median for segments of at most 1024 samples
+// (time lines of a window, per-chunk channel runs): the segment's keys stay in
+// registers (16 per lane), each wave owns a 256-bin LDS histogram, and the
+// bucket search is a wave scan -- no workgroup-wide work per segment.  Four
+// segments per 256-thread workgroup; barriers are executed uniformly.
+// grid (ceil(R*G/4), W), block 256
+// ---------------------------------------------------------------------------
+#define MW_K 16   // register slots per lane of the largest instantiation (segments <= 1024)
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor(v, o, 64));
+    return v;
+}
+
+template <int KS, bool VEC4>   // KS register slots per lane: segments of at most 64 * KS samples
+__global__ void __launch_bounds__(256)
+k_median_wave(const float* __restrict__ data, const uint8_t* __restrict__ flags,
+              double* __restrict__ med, size_t WSd, size_t WSf, size_t RS, size_t ES,
+              const int64_t* __restrict__ seg_start, const int64_t* __restrict__ seg_len,
+              int R, int G) {
+    __shared__ unsigned hist[4][256];
+    const unsigned SENT = 0xFFFFFFFFu;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int seg = blockIdx.x * 4 + wave;
+    const bool live = seg < R * G;
+    const int row = live ? seg / G : 0, g = live ? seg % G : 0;
+    const size_t win = blockIdx.y;
+    const int len = live ? (int)seg_len[g] : 0;
+    const size_t rel = (size_t)row * RS + (size_t)seg_start[g] * ES;
+    const float* d = data + win * WSd + rel;
+    const uint8_t* f = flags + win * WSf + rel;
+    unsigned keys[KS];
+    unsigned nloc = 0;
+    if (VEC4) {
+        // rows are 16-byte aligned and a multiple of 4 long: float4 / uchar4 loads
+        // of the aligned groups covering the segment, samples outside it masked
+        // (a selection does not care which lane holds which sample)
+        const int mis = live ? (int)(seg_start[g] & 3) : 0;
+        const float* d4 = d - mis;
+        const uint8_t* f4 = f - mis;
+#pragma unroll
+        for (int u4 = 0; u4 < KS / 4; u4++) {
+            const int i = (u4 * 64 + lane) * 4;          // offset of the aligned group
+            float4 dv = make_float4(0.f, 0.f, 0.f, 0.f);
+            uchar4 fv = make_uchar4(1, 1, 1, 1);
+            if (i < len + mis) {
+                dv = *reinterpret_cast<const float4*>(d4 + i);
+                fv = *reinterpret_cast<const uchar4*>(f4 + i);
+            }
+            const int j = i - mis;                         // logical index of the group's first sample
+            const bool v0 = j >= 0 && j < len && !fv.x;
+            const bool v1 = j + 1 >= 0 && j + 1 < len && !fv.y;
+            const bool v2 = j + 2 >= 0 && j + 2 < len && !fv.z;
+            const bool v3 = j + 3 >= 0 && j + 3 < len && !fv.w;
+            keys[4 * u4 + 0] = v0 ? (__float_as_uint(dv.x) & 0x7FFFFFFFu) : SENT;
+            keys[4 * u4 + 1] = v1 ? (__float_as_uint(dv.y) & 0x7FFFFFFFu) : SENT;
+            keys[4 * u4 + 2] = v2 ? (__float_as_uint(dv.z) & 0x7FFFFFFFu) : SENT;
+            keys[4 * u4 + 3] = v3 ? (__float_as_uint(dv.w) & 0x7FFFFFFFu) : SENT;
+            nloc += (v0 ? 1 : 0) + (v1 ? 1 : 0) + (v2 ? 1 : 0) + (v3 ? 1 : 0);
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < KS; u++) {
+            int i = u * 64 + lane;
+            unsigned k = SENT;
+            if (i < len) {
+                size_t a = (size_t)i * ES;
+                if (!f[a]) { k = __float_as_uint(d[a]) & 0x7FFFFFFFu; nloc++; }
+            }
+            keys[u] = k;
+        }
+    }
+    const unsigned n = wave_sum_u32(nloc);
+    // Normalise the keys to their minimum and radix-select only the B
+    // significant bits of the spread: the leading digit then follows the
+    // sample distribution (a plain top byte of a float is its exponent, which
+    // puts almost every sample of a line into one or two bins and serialises
+    // the LDS atomics).
+    unsigned kmin = SENT, kmax = 0;
+#pragma unroll
+    for (int u = 0; u < KS; u++)
+        if (keys[u] != SENT) { kmin = min(kmin, keys[u]); kmax = max(kmax, keys[u]); }
+    kmin = ~wave_max_u32(~kmin);
+    kmax = wave_max_u32(kmax);
+    const int B = (n == 0 || kmax == kmin) ? 0 : 32 - __clz((int)(kmax - kmin));
+    const int P = (B + 7) >> 3;
+#pragma unroll
+    for (int u = 0; u < KS; u++)
+        if (keys[u] != SENT) keys[u] -= kmin;
+    unsigned prefix = 0, pmask = 0, kk = n >> 1;
+    unsigned* h = hist[wave];
+    for (int p = 0; p < 4; p++) {
+        const int shift = max(B - 8 * (p + 1), 0);
+        const bool act = p < P;
+        reinterpret_cast<uint4*>(h)[lane] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+        if (act) {
+#pragma unroll
+            for (int u = 0; u < KS; u++) {
+                unsigned k = keys[u];
+                if (k != SENT && (k & pmask) == prefix) atomicAdd(&h[(k >> shift) & 0xFFu], 1u);
+            }
+        }
+        __syncthreads();
+        if (act) {
+            uint4 hv = reinterpret_cast<uint4*>(h)[lane];
+            unsigned sacc = hv.x + hv.y + hv.z + hv.w;
+            unsigned inc = sacc;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                unsigned v = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += v;
+            }
+            unsigned exc = inc - sacc;
+            bool mine = n > 0 && kk >= exc && kk < inc;
+            unsigned dsel = 0, cbase = exc;
+            if (mine) {
+                if (kk < exc + hv.x) dsel = 0;
+                else if (kk < exc + hv.x + hv.y) { dsel = 1; cbase = exc + hv.x; }
+                else if (kk < exc + hv.x + hv.y + hv.z) { dsel = 2; cbase = exc + hv.x + hv.y; }
+                else { dsel = 3; cbase = exc + hv.x + hv.y + hv.z; }
+            }
+            unsigned long long bm = __ballot(mine);
+            if (bm) {
+                int src = __ffsll((long long)bm) - 1;
+                unsigned digit = __shfl(4u * lane + dsel, src, 64);
+                unsigned base = __shfl(cbase, src, 64);
+                prefix |= digit << shift;   // overlapping bits of a short last digit are already equal
+                kk -= base;
+            }
+            pmask |= 0xFFu << shift;
+        }
+        __syncthreads();
+    }
+    unsigned cnt = 0, mx = 0;
+#pragma unroll
+    for (int u = 0; u < KS; u++) {
+        unsigned k = keys[u];
+        if (k != SENT && k < prefix) { cnt++; mx = max(mx, k); }
+    }
+    cnt = wave_sum_u32(cnt);
+    mx = wave_max_u32(mx) + kmin;
+    const unsigned hi = prefix + kmin;
+    if (live && lane == 0) {
+        size_t oidx = (win * (size_t)R + row) * G + g;
+        double m;
+        if (n == 0) m = __longlong_as_double(0x7FF8000000000000LL);
+        else if (n & 1u) m = (double)__uint_as_float(hi);
+        else {
+            unsigned lo = (cnt == (n >> 1)) ? mx : hi;
+            float sm = __uint_as_float(lo) + __uint_as_float(hi);
+            m = (double)sm / 2.0;
+        }
+        med[oidx] = m;
+    }
+}
+
+// spec_data[f][w] / spec_flags from the per-channel time medians
+// (flagging.py:258-263): none unflagged -> 0 and flagged.
+// med layout [w][f]; outputs in spectrum layout [Fa][Wn].
+__global__ void k_spec_from_med(const double* __restrict__ med, float* __restrict__ sdata,
+                                uint8_t* __restrict__ sflags, int Fa, int Wn) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)Fa * Wn) return;
+    int f = (int)(idx / Wn), w = (int)(idx % Wn);
+    double m = med[(size_t)w * Fa + f];
+    bool none = isnan(m);
+    sdata[idx] = none ? 0.0f : (float)m;
+    sflags[idx] = none ? 1 : 0;
+}
+

@@ -1,0 +1,291 @@
+// kernels_sumthreshold.hpp -- fused multi-window SumThreshold column kernels
+// Part of the single translation unit tricolour_amd.hip (see there for the overview).
+#pragma once
+
+// ---------------------------------------------------------------------------
+// K7  _sum_threshold1d + _convolve_flags (flagging.py:582-681) along the line
+// axis of [L][C]: one thread per (column, chunk) streams down its padded line
+// ONCE, running all windows as a cascade: stage j ingests position i (clamp
+// with the flags of stages < j, float64 sequential prefix sum), forms the
+// rolling sum S_k = cum[k+w] - cum[k] for k = i + 1 - w from a ring of the
+// last w prefix values, thresholds +S and -S against thr0 / rho^log2(w), and
+// dilates hits over w samples; stage j+1 runs w_j - 1 positions behind so
+// that its clamp sees exactly the flags the reference's window loop would
+// (flagging.py:638-674, window order as given).  Every float64 value is
+// produced by the same operations in the same order as the reference.
+// Input flags are used only in the MAD (flagging.py:622), never OR-ed in.
+//
+// Dynamic variant: arbitrary windows; prefix rings and the position ring of
+// accumulated (pos,neg) bits live in a global scratch laid out
+// [slot][thread] (coalesced).
+// grid (ceil(C/BLK), G, W), block BLK
+// ---------------------------------------------------------------------------
+struct StWin {
+    int nw;
+    int w[TRI_MAX_WINDOWS];
+    double tf[TRI_MAX_WINDOWS];     // rho ** log2(w)           (host libm, flagging.py:641)
+    double scale[TRI_MAX_WINDOWS];  // (double)(float)(1.0 / w) (flagging.py:664)
+    int ringoff[TRI_MAX_WINDOWS];   // slot offset of stage j's prefix ring
+    int ringtot;                    // sum of w
+    int delay[TRI_MAX_WINDOWS + 1]; // D_j = sum_{j'<j} (w_j' - 1)
+    int acccap;                     // >= D_nw + 1
+    int maxw;
+};
+
+__global__ void __launch_bounds__(256)
+k_colst_dyn(const float* __restrict__ data, const double* __restrict__ med,
+            uint8_t* __restrict__ out, double* __restrict__ ringbuf,
+            uint8_t* __restrict__ accbuf, const int64_t* __restrict__ chunk_ends, StWin sw,
+            double thr_scale, int L, int C, int G, size_t ws_data, size_t ws_out) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    int g = blockIdx.y;
+    size_t win = blockIdx.z;
+    int c0 = (int)chunk_ends[g], c1 = (int)chunk_ends[g + 1];
+    if (c1 <= c0) return;
+    // thread-private scratch, [slot][thread]
+    size_t nthreads = (size_t)gridDim.z * G * C;
+    size_t tidg = (win * G + g) * (size_t)C + c;
+    double* ring = ringbuf + tidg;
+    uint8_t* acc = accbuf + tidg;
+    const float* x = data + win * ws_data + c;
+    uint8_t* o = out + win * ws_out + c;
+    const size_t Cs = (size_t)C;
+
+    // flagging.py:622-628
+    float mad = (float)med[(win * (size_t)C + c) * G + g];
+    float thr0 = isnan(mad) ? INFINITY : (float)((double)mad * thr_scale);
+    // flagging.py:630-633 (slicing clamps to the axis length)
+    int p0 = max(c0 - sw.maxw + 1, 0);
+    int p1 = min(c1 + sw.maxw - 1, L);
+    int Lp = p1 - p0;
+
+    const int nw = sw.nw;
+    double thr[TRI_MAX_WINDOWS], cumlast[TRI_MAX_WINDOWS];
+    int sincep[TRI_MAX_WINDOWS], sincen[TRI_MAX_WINDOWS];
+    for (int j = 0; j < nw; j++) {
+        thr[j] = (double)thr0 / sw.tf[j];
+        cumlast[j] = 0.0;
+        sincep[j] = sincen[j] = 1 << 30;
+        ring[(size_t)sw.ringoff[j] * nthreads] = 0.0;  // cum[0] = 0 in slot 0
+    }
+    for (int s = 0; s < sw.acccap; s++) acc[(size_t)s * nthreads] = 0;
+
+    const int total = Lp + sw.delay[nw];
+    for (int n = 0; n < total; n++) {
+        for (int j = 0; j < nw; j++) {
+            const int w = sw.w[j];
+            int i = n - sw.delay[j];      // ingest position
+            if (i < 0) continue;
+            int e = i + 1 - w;            // emit position
+            if (e >= Lp) continue;
+            bool hp = false, hn = false;
+            if (i < Lp) {
+                uint8_t a = acc[(size_t)(i % sw.acccap) * nthreads];
+                float xf = x[(size_t)(p0 + i) * Cs];
+                double clamped = (double)xf;
+                double limit = thr[j];
+                if ((a & 1) && clamped > limit) clamped = limit;
+                else if ((a & 2) && clamped < -limit) clamped = -limit;
+                double cumnew = cumlast[j] + clamped;
+                cumlast[j] = cumnew;
+                size_t slot = (size_t)(sw.ringoff[j] + ((i + 1) % w)) * nthreads;
+                if (e >= 0) {
+                    double S = cumnew - ring[slot];
+                    hp = S * sw.scale[j] > limit;
+                    hn = S * (-sw.scale[j]) > limit;
+                }
+                ring[slot] = cumnew;
+            }
+            if (e >= 0) {
+                sincep[j] = hp ? 0 : min(sincep[j] + 1, 1 << 30);
+                sincen[j] = hn ? 0 : min(sincen[j] + 1, 1 << 30);
+                uint8_t add = (sincep[j] < w ? 1 : 0) | (sincen[j] < w ? 2 : 0);
+                if (add) acc[(size_t)(e % sw.acccap) * nthreads] |= add;
+            }
+        }
+        int ef = n - sw.delay[nw];        // position final after the last stage
+        if (ef >= 0 && ef < Lp) {
+            size_t aslot = (size_t)(ef % sw.acccap) * nthreads;
+            uint8_t a = acc[aslot];
+            acc[aslot] = 0;               // recycle the slot
+            int pos = p0 + ef;
+            if (pos >= c0 && pos < c1) o[(size_t)pos * Cs] = a ? 1 : 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K7b  Register-resident SumThreshold cascade for power-of-two windows
+// {W0,W1,W2,W3} with W3 <= 8 (the library default and every shipped strategy's
+// time axis: 1,2,4,8).  Same arithmetic as k_colst_dyn, but
+//   * the prefix rings (w doubles per stage), the 8-deep sample ring and the
+//     hit / input-flag histories (bit shift registers) live in VGPRs: the tick
+//     loop is unrolled by 8 so that every ring index is a compile-time
+//     constant;
+//   * stage j+1 runs w_j positions behind stage j (one more than necessary),
+//     so the flag hand-off crosses a tick boundary and the four stages of one
+//     tick are independent instruction streams;
+//   * for a power-of-two window, S * f32(1/w) > thr  <=>  S > thr * w exactly
+//     (both sides scale by 2^k; S is a multiple of 2^-203 or larger, far above
+//     the underflow range), so the threshold tests need no multiply.
+// One thread per (column, chunk); HBM traffic = 4 B in + 1 B out per sample.
+// grid (ceil(C/BLK), G, W), block BLK
+// ---------------------------------------------------------------------------
+struct StFusedArgs {
+    double tf[4];   // rho ** log2(w)
+};
+
+#ifndef ST_WAVES
+#define ST_WAVES 2
+#endif
+template <int W0, int W1, int W2, int W3>
+__global__ void __launch_bounds__(256, ST_WAVES)
+k_colst_fused(const float* __restrict__ data, const double* __restrict__ med,
+              uint8_t* __restrict__ out, const int64_t* __restrict__ chunk_ends,
+              StFusedArgs fa, double thr_scale, int L, int C, int G, size_t ws_data,
+              size_t ws_out) {
+    constexpr int W[4] = {W0, W1, W2, W3};
+    constexpr int D[4] = {0, W0, W0 + W1, W0 + W1 + W2};   // ingest delay of stage j
+    constexpr int DOUT = W0 + W1 + W2 + W3 - 1;             // final flags lag the head by this
+    constexpr int MAXW = W3;
+    constexpr int UN = 16;                                   // ticks per unrolled block
+    static_assert(W0 <= W1 && W1 <= W2 && W2 <= W3 && W3 <= 8, "windows must be sorted, <= 8");
+    static_assert((W0 & (W0 - 1)) == 0 && (W1 & (W1 - 1)) == 0 && (W2 & (W2 - 1)) == 0 &&
+                  (W3 & (W3 - 1)) == 0, "power-of-two windows");
+    static_assert(W0 + W1 + W2 <= 7, "sample ring is 8 deep");
+    static_assert(DOUT < UN, "flag ring is 16 deep");
+
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int g = blockIdx.y;
+    const size_t win = blockIdx.z;
+    const int c0 = (int)chunk_ends[g], c1 = (int)chunk_ends[g + 1];
+    if (c1 <= c0) return;
+    const float* x = data + win * ws_data + c;
+    uint8_t* o = out + win * ws_out + c;
+    const size_t Cs = (size_t)C;
+
+    float mad = (float)med[(win * (size_t)C + c) * G + g];
+    float thr0 = isnan(mad) ? INFINITY : (float)((double)mad * thr_scale);
+    const int p0 = max(c0 - MAXW + 1, 0);
+    const int p1 = min(c1 + MAXW - 1, L);
+    const int Lp = p1 - p0;
+    const int o0 = c0 - p0, o1 = c1 - p0;   // output interior in padded coordinates
+    x += (size_t)p0 * Cs;
+    o += (size_t)p0 * Cs;
+
+    // thr = f64(thr0) / rho^log2(w) (flagging.py:643); T = thr * w (exact);
+    // lim = largest float32 <= thr, so that for a float32 sample xf
+    //   (double)xf > thr  <=>  xf > lim     and    (double)xf < -thr  <=>  xf < -lim
+    double thr[4], T[4];
+    float lim[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        thr[j] = (double)thr0 / fa.tf[j];
+        T[j] = thr[j] * (double)W[j];
+        float l = (float)thr[j];
+        if ((double)l > thr[j]) {   // rounded up: step to the next float32 below
+            unsigned b = __float_as_uint(l);
+            b = (l > 0.0f) ? b - 1u : ((l < 0.0f) ? b + 1u : 0x80000001u);
+            l = __uint_as_float(b);
+        }
+        lim[j] = l;
+    }
+    double cumlast[4] = {0.0, 0.0, 0.0, 0.0};
+    double r0[W0], r1[W1], r2[W2], r3[W3];
+#pragma unroll
+    for (int k = 0; k < W0; k++) r0[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < W1; k++) r1[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < W2; k++) r2[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < W3; k++) r3[k] = 0.0;
+    // tick of the last positive / negative hit of stage j (far past: none in reach)
+    int sp[4] = {-64, -64, -64, -64}, sn[4] = {-64, -64, -64, -64};
+    // accumulated flags by position (mod 16): stage j ORs its dilated hits in,
+    // stage j+1 reads them for its clamp, the last stage's position is output
+    unsigned accP[UN], accN[UN];
+#pragma unroll
+    for (int k = 0; k < UN; k++) { accP[k] = 0; accN[k] = 0; }
+    float xf[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) xf[k] = 0.0f;
+
+    const int nticks = Lp + DOUT;
+    float cur[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) cur[u] = (u < Lp) ? x[(size_t)u * Cs] : 0.0f;
+
+    auto block = [&](auto fastc, const int base) {
+        constexpr bool fast = decltype(fastc)::value;
+#pragma unroll
+        for (int PH = 0; PH < UN; PH++) {
+            const int n = base + PH;
+            xf[PH & 7] = cur[PH];
+            // rolling prefetch: the slot just consumed is refilled 16 ticks ahead
+            cur[PH] = (n + UN < Lp) ? x[(size_t)(n + UN) * Cs] : 0.0f;
+            // stages in reverse order: stage j reads the flags stage j-1 wrote
+            // at the previous tick
+#pragma unroll
+            for (int j = 3; j >= 0; j--) {
+#ifdef ST_EXP_STAGES
+                if (j >= ST_EXP_STAGES) continue;
+#endif
+                const int w = W[j];
+                const int i = n - D[j];        // ingest position
+                const int e = i + 1 - w;       // emit position
+                const bool ing = fast || (i >= 0 && i < Lp);
+                const bool emi = fast || (e >= 0 && e < Lp);
+                bool hp = false, hn = false;
+                if (ing) {
+                    const float xs = xf[(PH - D[j]) & 7];
+                    double cl = (double)xs;
+                    if (j > 0) {
+                        const bool cp = (accP[(PH - D[j]) & (UN - 1)] != 0) && (xs > lim[j]);
+                        const bool cn = !cp && (accN[(PH - D[j]) & (UN - 1)] != 0) && (xs < -lim[j]);
+                        cl = cp ? thr[j] : (cn ? -thr[j] : cl);
+                    }
+                    const double cum = cumlast[j] + cl;
+                    cumlast[j] = cum;
+                    const int slot = (PH - D[j] + 1) & (w - 1);
+                    double old;
+                    if (j == 0) { old = r0[slot & (W0 - 1)]; r0[slot & (W0 - 1)] = cum; }
+                    else if (j == 1) { old = r1[slot & (W1 - 1)]; r1[slot & (W1 - 1)] = cum; }
+                    else if (j == 2) { old = r2[slot & (W2 - 1)]; r2[slot & (W2 - 1)] = cum; }
+                    else { old = r3[slot & (W3 - 1)]; r3[slot & (W3 - 1)] = cum; }
+                    const double S = cum - old;
+                    const bool valid = fast || e >= 0;
+                    hp = valid && (S > T[j]);
+                    hn = valid && (S < -T[j]);
+                }
+                if (emi) {
+                    bool ap, an;
+                    if (w == 1) { ap = hp; an = hn; }
+                    else {
+                        sp[j] = hp ? n : sp[j];      // tick of the last hit
+                        sn[j] = hn ? n : sn[j];
+                        ap = sp[j] > n - w;
+                        an = sn[j] > n - w;
+                    }
+                    const int es = (PH - D[j] + 1 - w) & (UN - 1);
+                    accP[es] = ap ? 1u : accP[es];
+                    accN[es] = an ? 1u : accN[es];
+                }
+            }
+            const int ef = n - DOUT;
+            const int fs = (PH - DOUT) & (UN - 1);
+            if (fast || (ef >= o0 && ef < o1)) o[(size_t)ef * Cs] = (uint8_t)(accP[fs] | accN[fs]);
+            accP[fs] = 0;
+            accN[fs] = 0;
+        }
+    };
+
+    for (int base = 0; base < nticks; base += UN) {
+        const bool fast = base >= UN && base + UN - 1 < Lp && base - DOUT >= o0 && base + UN - 1 - DOUT < o1;
+        if (fast) block(std::true_type{}, base);
+        else block(std::false_type{}, base);
+    }
+}
+

@@ -1,1882 +1,15 @@
-// tricolour_amd.hip -- MI355X (gfx950 / CDNA4) SumThreshold RFI flagger.
-//
-// Hand-written HIP implementation of the hot path of ratt-ru/tricolour
-// (reference tricolour/flagging.py:175-976, 1076-1196; packing.py:243-278,
-// 369-415) behind the C ABI of include/tricolour_amd.h.  Not a translation:
-// the reference is a serial per-baseline numba loop nest; here every step is a
-// batched kernel over (window, line) with the window held in HBM in BOTH
-// orientations -- "TF" (time rows, channel columns) and "FT" (channel rows,
-// time columns) -- so that
-//   * every sequential float64 recurrence of the reference (box-filter running
-//     sums, SumThreshold prefix sums, NaN interpolation) runs one thread per
-//     line with the line index on the coalesced axis ("column kernels"), in
-//     exactly the reference's order of operations => bit-exact by
-//     construction, and
-//   * every exact median runs over lines that are contiguous in memory
-//     ("row select": multi-pass radix select on the |x| bit patterns).
-// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no fast-math: the
-// results must follow IEEE evaluation order).
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdint>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <type_traits>
-#include <vector>
-
-#include "../../include/tricolour_amd.h"
-
-#define TRI_MAD_NORMAL 1.4826  // flagging.py:22
-
-// ---------------------------------------------------------------------------
-// error plumbing
-// ---------------------------------------------------------------------------
-static thread_local char g_err[1024] = "";
-
-static int set_err(int code, const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-    return code;
-}
-
-#define HIPCHK(expr)                                                          \
-    do {                                                                      \
-        hipError_t e__ = (expr);                                              \
-        if (e__ != hipSuccess)                                                \
-            return set_err(TRI_EHIP, "%s failed: %s (%s:%d)", #expr,          \
-                           hipGetErrorString(e__), __FILE__, __LINE__);       \
-    } while (0)
-
-#define LAUNCHCHK()                                                           \
-    do {                                                                      \
-        hipError_t e__ = hipGetLastError();                                   \
-        if (e__ != hipSuccess)                                                \
-            return set_err(TRI_EHIP, "kernel launch failed: %s (%s:%d)",      \
-                           hipGetErrorString(e__), __FILE__, __LINE__);       \
-    } while (0)
-
-extern "C" const char* tri_last_error(void) { return g_err; }
-extern "C" int tri_version(void) { return 100; }
-
-static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
-
-// ---------------------------------------------------------------------------
-// device helpers
-// ---------------------------------------------------------------------------
-// |complex64| with libm hypotf semantics (numba lowers abs(complex64) to
-// hypotf, flagging.py:856): glibc evaluates (float)sqrt((double)x*x +
-// (double)y*y) with the C99 infinity rule.  Products are exact in float64, one
-// rounding in the sum, IEEE sqrt, one narrowing cast.
-__device__ __forceinline__ float tri_hypotf(float re, float im) {
-    if (isinf(re) || isinf(im)) return INFINITY;
-    double s = (double)re * (double)re + (double)im * (double)im;
-    return (float)sqrt(s);
-}
-
-template <int VD>
-__device__ __forceinline__ float load_amp(const void* vis, size_t i) {
-    if (VD == TRI_VIS_C64) {
-        float2 z = reinterpret_cast<const float2*>(vis)[i];
-        return tri_hypotf(z.x, z.y);
-    } else {
-        return fabsf(reinterpret_cast<const float*>(vis)[i]);
-    }
-}
-
-template <int VD>
-__device__ __forceinline__ bool load_isnan(const void* vis, size_t i) {
-    if (VD == TRI_VIS_C64) {
-        float2 z = reinterpret_cast<const float2*>(vis)[i];
-        return isnan(z.x) || isnan(z.y);
-    } else {
-        return isnan(reinterpret_cast<const float*>(vis)[i]);
-    }
-}
-
-// ---------------------------------------------------------------------------
-// K1  _average_freq (flagging.py:819-875): |vis| -> f32, NaN -> flagged,
-// flagged -> 0, channel averaging by `factor` (f32 accumulation in ascending
-// channel order, f32 / count).  One thread per averaged sample.
-// grid (ceil(T*Fa/256), W)
-// ---------------------------------------------------------------------------
-template <int VD>
-__global__ void k_prepare(const void* __restrict__ vis, const uint8_t* __restrict__ iflags,
-                          float* __restrict__ data, uint8_t* __restrict__ flags,
-                          int T, int F, int Fa, int factor) {
-    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t NA = (size_t)T * Fa;
-    if (idx >= NA) return;
-    int t = (int)(idx / Fa), fo = (int)(idx % Fa);
-    size_t w = blockIdx.y;
-    size_t base = w * (size_t)T * F + (size_t)t * F;
-    int f0 = fo * factor;
-    int f1 = min(F, f0 + factor);
-    float sum = 0.0f;
-    int cnt = 0;
-    for (int f = f0; f < f1; f++) {
-        float a = load_amp<VD>(vis, base + f);
-        if (!iflags[base + f] && !isnan(a)) { sum += a; cnt++; }
-    }
-    size_t o = w * NA + idx;
-    if (cnt == 0) { data[o] = 0.0f; flags[o] = 1; }
-    else { data[o] = sum / (float)cnt; flags[o] = 0; }
-}
-
-__global__ void k_abs_c64(const float2* __restrict__ z, float* __restrict__ out, size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = tri_hypotf(z[i].x, z[i].y);
-}
-
-// ---------------------------------------------------------------------------
-// K2  batched tiled transpose  src[W][R][C] -> dst[W][C][R]  (64x64 LDS tile)
-// grid (ceil(C/64), ceil(R/64), W), block (64,4)
-// ---------------------------------------------------------------------------
-// `denom` != 0 (float images only): the stored value is x / denom -- the
-// final division of _box_gaussian_filter1d (flagging.py:419), deferred from
-// the latency-bound sequential filter kernel to this bandwidth-bound copy.
-template <typename T>
-__global__ void k_transpose(const T* __restrict__ src, T* __restrict__ dst, int R, int C,
-                            size_t src_ws, size_t dst_ws, float denom) {
-    __shared__ T tile[64][65];
-    const T* s = src + (size_t)blockIdx.z * src_ws;
-    T* d = dst + (size_t)blockIdx.z * dst_ws;
-    int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
-    int tx = threadIdx.x, ty = threadIdx.y;
-    for (int j = ty; j < 64; j += 4) {
-        int r = r0 + j, c = c0 + tx;
-        if (r < R && c < C) tile[j][tx] = s[(size_t)r * C + c];
-    }
-    __syncthreads();
-    for (int j = ty; j < 64; j += 4) {
-        int c = c0 + j, r = r0 + tx;
-        if (r < R && c < C) {
-            T v = tile[tx][j];
-            if (sizeof(T) == 4 && denom != 0.0f) v = (T)((float)v / denom);
-            d[(size_t)c * R + r] = v;
-        }
-    }
-}
-
-// uint8 transpose with 4-byte accesses on both sides (R % 4 == 0, C % 4 == 0):
-// 64x64 byte tile; thread (tx, ty) of a (16,16) block moves uchar4 groups.
-__global__ void k_transpose_u8x4(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int R,
-                                 int C, size_t src_ws, size_t dst_ws) {
-    __shared__ uint8_t tile[64][68];
-    const uint8_t* s = src + (size_t)blockIdx.z * src_ws;
-    uint8_t* d = dst + (size_t)blockIdx.z * dst_ws;
-    int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
-    int tx = threadIdx.x, ty = threadIdx.y;   // 16 x 16
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        int r = r0 + ty + 16 * j, c = c0 + 4 * tx;
-        uchar4 v = make_uchar4(0, 0, 0, 0);
-        if (r < R && c < C) v = *reinterpret_cast<const uchar4*>(s + (size_t)r * C + c);
-        *reinterpret_cast<uchar4*>(&tile[ty + 16 * j][4 * tx]) = v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        int c = c0 + ty + 16 * j, r = r0 + 4 * tx;   // output row = source column
-        if (c < C && r < R) {
-            int cc = ty + 16 * j;
-            uchar4 v = make_uchar4(tile[4 * tx][cc], tile[4 * tx + 1][cc], tile[4 * tx + 2][cc], tile[4 * tx + 3][cc]);
-            *reinterpret_cast<uchar4*>(d + (size_t)c * R + r) = v;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// K3  segmented exact median of |x| over unflagged samples ("row select").
-// np.median under numba (np/arraymath.py:1365-1399): odd n -> middle element,
-// even n -> f32(a + b) / 2 in float64.  NaN when nothing is unflagged
-// (flagging.py:276-277, 300-301).  |x| of a float32 is a sign-bit clear, so
-// ordering |x| = ordering the low 31 bits as unsigned integers: a 4-digit
-// (7+8+8+8 bit) radix select is exact.
-// One workgroup per segment.  Segment (win, row, g) covers elements
-//   data[win*WSd + row*RS + (seg_start[g] + i)*ES],  i < seg_len[g]
-// (flags likewise with window stride WSf).
-// Output med[(win*R + row)*G + g] (float64).
-// grid (R*G, W), block 256
-// ---------------------------------------------------------------------------
-#define SEL_CACHE 8
-#define SEL_BINS 2048
-// Three radix passes over the 31-bit key: digits of 11, 10 and 10 bits.  The
-// even-count partner (rank n/2 - 1) needs no extra pass: it equals the median
-// key when that key is duplicated below rank n/2, else the largest occupied
-// bin below it in the last histogram, else the largest key with a smaller
-// 21-bit prefix (tracked during the last pass).
-// VEC: segments are contiguous, 16-byte aligned and a multiple of 4 long ->
-// float4 / uchar4 loads.
-template <bool VEC>
-__global__ void __launch_bounds__(256)
-k_median(const float* __restrict__ data, const uint8_t* __restrict__ flags,
-         double* __restrict__ med, size_t WSd, size_t WSf, size_t RS, size_t ES,
-         const int64_t* __restrict__ seg_start, const int64_t* __restrict__ seg_len,
-         int R, int G) {
-    __shared__ unsigned hist[SEL_BINS];
-    __shared__ unsigned sh_wsum[4];
-    __shared__ unsigned sh_prefix, sh_k, sh_sel, sh_maxbelow, sh_lobin1;
-    const unsigned SENT = 0xFFFFFFFFu;
-    int seg = blockIdx.x;
-    int row = seg / G, g = seg % G;
-    size_t win = blockIdx.y;
-    int64_t len = seg_len[g];
-    size_t rel = (size_t)row * RS + (size_t)seg_start[g] * ES;
-    data += win * WSd + rel;
-    flags += win * WSf + rel;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool cached = !VEC && len <= (int64_t)SEL_CACHE * 256;
-    unsigned keys[SEL_CACHE];
-    if (cached) {
-#pragma unroll
-        for (int u = 0; u < SEL_CACHE; u++) {
-            int64_t i = (int64_t)u * 256 + tid;
-            unsigned k = SENT;
-            if (i < len) {
-                size_t a = (size_t)i * ES;
-                if (!flags[a]) k = __float_as_uint(data[a]) & 0x7FFFFFFFu;
-            }
-            keys[u] = k;
-        }
-    }
-    if (tid == 0) { sh_maxbelow = 0; sh_lobin1 = 0; }
-    unsigned prefix = 0, pmask = 0, kk = 0, n = 0;
-    for (int p = 0; p < 3; p++) {
-        const int shift = p == 0 ? 20 : (p == 1 ? 10 : 0);
-        const unsigned dm = p == 0 ? 0x7FFu : 0x3FFu;
-#pragma unroll
-        for (int u = 0; u < SEL_BINS / 256; u++) hist[u * 256 + tid] = 0;
-        __syncthreads();
-        unsigned mb = 0;
-        auto visit = [&](unsigned k) {
-            if ((k & pmask) == prefix) atomicAdd(&hist[(k >> shift) & dm], 1u);
-            else if (p == 2 && k < prefix) mb = max(mb, k);
-        };
-        if (cached) {
-#pragma unroll
-            for (int u = 0; u < SEL_CACHE; u++)
-                if (keys[u] != SENT) visit(keys[u]);
-        } else if (VEC) {
-            const float4* d4 = reinterpret_cast<const float4*>(data);
-            const uchar4* f4 = reinterpret_cast<const uchar4*>(flags);
-            for (int64_t i = tid; i < len / 4; i += 256) {
-                float4 dv = d4[i];
-                uchar4 fv = f4[i];
-                if (!fv.x) visit(__float_as_uint(dv.x) & 0x7FFFFFFFu);
-                if (!fv.y) visit(__float_as_uint(dv.y) & 0x7FFFFFFFu);
-                if (!fv.z) visit(__float_as_uint(dv.z) & 0x7FFFFFFFu);
-                if (!fv.w) visit(__float_as_uint(dv.w) & 0x7FFFFFFFu);
-            }
-        } else {
-            for (int64_t i = tid; i < len; i += 256) {
-                size_t a = (size_t)i * ES;
-                if (!flags[a]) visit(__float_as_uint(data[a]) & 0x7FFFFFFFu);
-            }
-        }
-        if (p == 2 && mb) atomicMax(&sh_maxbelow, mb);
-        __syncthreads();
-        // bucket search: thread t owns bins [8t, 8t+8)
-        unsigned v[8];
-        {
-            uint4 q0 = reinterpret_cast<const uint4*>(hist)[2 * tid];
-            uint4 q1 = reinterpret_cast<const uint4*>(hist)[2 * tid + 1];
-            v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w;
-            v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
-        }
-        unsigned sacc = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) sacc += v[j];
-        unsigned inc = sacc;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            unsigned t2 = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += t2;
-        }
-        if (lane == 63) sh_wsum[wave] = inc;
-        __syncthreads();
-        unsigned woff = 0, total = 0;
-#pragma unroll
-        for (int w2 = 0; w2 < 4; w2++) {
-            unsigned t2 = sh_wsum[w2];
-            if (w2 < wave) woff += t2;
-            total += t2;
-        }
-        if (p == 0) { n = total; kk = total >> 1; }
-        unsigned exc = woff + inc - sacc;
-        if (total > 0 && kk >= exc && kk < exc + sacc) {
-            unsigned c = exc;
-            int j = 0;
-#pragma unroll
-            for (int q = 0; q < 7; q++)
-                if (j == q && kk >= c + v[q]) { c += v[q]; j = q + 1; }
-            sh_sel = 8u * tid + j;
-            sh_prefix = prefix | ((8u * tid + j) << shift);
-            sh_k = kk - c;
-        }
-        __syncthreads();
-        if (n == 0) break;
-        if (p == 2) {
-            unsigned sel = sh_sel, cand = 0;
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-                if (v[j] && 8u * tid + j < sel) cand = 8u * tid + j + 1;
-            if (cand) atomicMax(&sh_lobin1, cand);
-        }
-        prefix = sh_prefix;
-        kk = sh_k;
-        pmask |= dm << shift;
-        __syncthreads();
-    }
-    if (tid == 0) {
-        size_t oidx = (win * (size_t)R + row) * G + g;
-        double m;
-        if (n == 0) m = __longlong_as_double(0x7FF8000000000000LL);
-        else if (n & 1u) m = (double)__uint_as_float(prefix);
-        else {
-            unsigned hi = prefix, lo;
-            if (kk > 0) lo = hi;
-            else if (sh_lobin1) lo = (hi & ~0x3FFu) | (sh_lobin1 - 1);
-            else lo = sh_maxbelow;
-            float sm = __uint_as_float(lo) + __uint_as_float(hi);
-            m = (double)sm / 2.0;
-        }
-        med[oidx] = m;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// K3b  Wave-per-segment form of k_median for segments of at most 1024 samples
-// (time lines of a window, per-chunk channel runs): the segment's keys stay in
-// registers (16 per lane), each wave owns a 256-bin LDS histogram, and the
-// bucket search is a wave scan -- no workgroup-wide work per segment.  Four
-// segments per 256-thread workgroup; barriers are executed uniformly.
-// grid (ceil(R*G/4), W), block 256
-// ---------------------------------------------------------------------------
-#define MW_K 16   // register slots per lane of the largest instantiation (segments <= 1024)
-__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor(v, o, 64));
-    return v;
-}
-
-template <int KS, bool VEC4>   // KS register slots per lane: segments of at most 64 * KS samples
-__global__ void __launch_bounds__(256)
-k_median_wave(const float* __restrict__ data, const uint8_t* __restrict__ flags,
-              double* __restrict__ med, size_t WSd, size_t WSf, size_t RS, size_t ES,
-              const int64_t* __restrict__ seg_start, const int64_t* __restrict__ seg_len,
-              int R, int G) {
-    __shared__ unsigned hist[4][256];
-    const unsigned SENT = 0xFFFFFFFFu;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int seg = blockIdx.x * 4 + wave;
-    const bool live = seg < R * G;
-    const int row = live ? seg / G : 0, g = live ? seg % G : 0;
-    const size_t win = blockIdx.y;
-    const int len = live ? (int)seg_len[g] : 0;
-    const size_t rel = (size_t)row * RS + (size_t)seg_start[g] * ES;
-    const float* d = data + win * WSd + rel;
-    const uint8_t* f = flags + win * WSf + rel;
-    unsigned keys[KS];
-    unsigned nloc = 0;
-    if (VEC4) {
-        // rows are 16-byte aligned and a multiple of 4 long: float4 / uchar4 loads
-        // of the aligned groups covering the segment, samples outside it masked
-        // (a selection does not care which lane holds which sample)
-        const int mis = live ? (int)(seg_start[g] & 3) : 0;
-        const float* d4 = d - mis;
-        const uint8_t* f4 = f - mis;
-#pragma unroll
-        for (int u4 = 0; u4 < KS / 4; u4++) {
-            const int i = (u4 * 64 + lane) * 4;          // offset of the aligned group
-            float4 dv = make_float4(0.f, 0.f, 0.f, 0.f);
-            uchar4 fv = make_uchar4(1, 1, 1, 1);
-            if (i < len + mis) {
-                dv = *reinterpret_cast<const float4*>(d4 + i);
-                fv = *reinterpret_cast<const uchar4*>(f4 + i);
-            }
-            const int j = i - mis;                         // logical index of the group's first sample
-            const bool v0 = j >= 0 && j < len && !fv.x;
-            const bool v1 = j + 1 >= 0 && j + 1 < len && !fv.y;
-            const bool v2 = j + 2 >= 0 && j + 2 < len && !fv.z;
-            const bool v3 = j + 3 >= 0 && j + 3 < len && !fv.w;
-            keys[4 * u4 + 0] = v0 ? (__float_as_uint(dv.x) & 0x7FFFFFFFu) : SENT;
-            keys[4 * u4 + 1] = v1 ? (__float_as_uint(dv.y) & 0x7FFFFFFFu) : SENT;
-            keys[4 * u4 + 2] = v2 ? (__float_as_uint(dv.z) & 0x7FFFFFFFu) : SENT;
-            keys[4 * u4 + 3] = v3 ? (__float_as_uint(dv.w) & 0x7FFFFFFFu) : SENT;
-            nloc += (v0 ? 1 : 0) + (v1 ? 1 : 0) + (v2 ? 1 : 0) + (v3 ? 1 : 0);
-        }
-    } else {
-#pragma unroll
-        for (int u = 0; u < KS; u++) {
-            int i = u * 64 + lane;
-            unsigned k = SENT;
-            if (i < len) {
-                size_t a = (size_t)i * ES;
-                if (!f[a]) { k = __float_as_uint(d[a]) & 0x7FFFFFFFu; nloc++; }
-            }
-            keys[u] = k;
-        }
-    }
-    const unsigned n = wave_sum_u32(nloc);
-    // Normalise the keys to their minimum and radix-select only the B
-    // significant bits of the spread: the leading digit then follows the
-    // sample distribution (a plain top byte of a float is its exponent, which
-    // puts almost every sample of a line into one or two bins and serialises
-    // the LDS atomics).
-    unsigned kmin = SENT, kmax = 0;
-#pragma unroll
-    for (int u = 0; u < KS; u++)
-        if (keys[u] != SENT) { kmin = min(kmin, keys[u]); kmax = max(kmax, keys[u]); }
-    kmin = ~wave_max_u32(~kmin);
-    kmax = wave_max_u32(kmax);
-    const int B = (n == 0 || kmax == kmin) ? 0 : 32 - __clz((int)(kmax - kmin));
-    const int P = (B + 7) >> 3;
-#pragma unroll
-    for (int u = 0; u < KS; u++)
-        if (keys[u] != SENT) keys[u] -= kmin;
-    unsigned prefix = 0, pmask = 0, kk = n >> 1;
-    unsigned* h = hist[wave];
-    for (int p = 0; p < 4; p++) {
-        const int shift = max(B - 8 * (p + 1), 0);
-        const bool act = p < P;
-        reinterpret_cast<uint4*>(h)[lane] = make_uint4(0, 0, 0, 0);
-        __syncthreads();
-        if (act) {
-#pragma unroll
-            for (int u = 0; u < KS; u++) {
-                unsigned k = keys[u];
-                if (k != SENT && (k & pmask) == prefix) atomicAdd(&h[(k >> shift) & 0xFFu], 1u);
-            }
-        }
-        __syncthreads();
-        if (act) {
-            uint4 hv = reinterpret_cast<uint4*>(h)[lane];
-            unsigned sacc = hv.x + hv.y + hv.z + hv.w;
-            unsigned inc = sacc;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                unsigned v = __shfl_up(inc, o, 64);
-                if (lane >= o) inc += v;
-            }
-            unsigned exc = inc - sacc;
-            bool mine = n > 0 && kk >= exc && kk < inc;
-            unsigned dsel = 0, cbase = exc;
-            if (mine) {
-                if (kk < exc + hv.x) dsel = 0;
-                else if (kk < exc + hv.x + hv.y) { dsel = 1; cbase = exc + hv.x; }
-                else if (kk < exc + hv.x + hv.y + hv.z) { dsel = 2; cbase = exc + hv.x + hv.y; }
-                else { dsel = 3; cbase = exc + hv.x + hv.y + hv.z; }
-            }
-            unsigned long long bm = __ballot(mine);
-            if (bm) {
-                int src = __ffsll((long long)bm) - 1;
-                unsigned digit = __shfl(4u * lane + dsel, src, 64);
-                unsigned base = __shfl(cbase, src, 64);
-                prefix |= digit << shift;   // overlapping bits of a short last digit are already equal
-                kk -= base;
-            }
-            pmask |= 0xFFu << shift;
-        }
-        __syncthreads();
-    }
-    unsigned cnt = 0, mx = 0;
-#pragma unroll
-    for (int u = 0; u < KS; u++) {
-        unsigned k = keys[u];
-        if (k != SENT && k < prefix) { cnt++; mx = max(mx, k); }
-    }
-    cnt = wave_sum_u32(cnt);
-    mx = wave_max_u32(mx) + kmin;
-    const unsigned hi = prefix + kmin;
-    if (live && lane == 0) {
-        size_t oidx = (win * (size_t)R + row) * G + g;
-        double m;
-        if (n == 0) m = __longlong_as_double(0x7FF8000000000000LL);
-        else if (n & 1u) m = (double)__uint_as_float(hi);
-        else {
-            unsigned lo = (cnt == (n >> 1)) ? mx : hi;
-            float sm = __uint_as_float(lo) + __uint_as_float(hi);
-            m = (double)sm / 2.0;
-        }
-        med[oidx] = m;
-    }
-}
-
-// spec_data[f][w] / spec_flags from the per-channel time medians
-// (flagging.py:258-263): none unflagged -> 0 and flagged.
-// med layout [w][f]; outputs in spectrum layout [Fa][Wn].
-__global__ void k_spec_from_med(const double* __restrict__ med, float* __restrict__ sdata,
-                                uint8_t* __restrict__ sflags, int Fa, int Wn) {
-    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)Fa * Wn) return;
-    int f = (int)(idx / Wn), w = (int)(idx % Wn);
-    double m = med[(size_t)w * Fa + f];
-    bool none = isnan(m);
-    sdata[idx] = none ? 0.0f : (float)m;
-    sflags[idx] = none ? 1 : 0;
-}
-
-// ---------------------------------------------------------------------------
-// K4  _box_gaussian_filter1d (flagging.py:362-419) along the line axis of a
-// [n][C] array, one thread per (column, image): four running box sums of
-// width 2r+1 over a left-zero-padded line, float64 accumulator, every pass
-// stored as float32 -- in exactly the reference's order (add the leading
-// sample, store, subtract the trailing sample).  The padded line lives in a
-// global scratch buffer buf[P = n + 4r][C] and the passes run in place, as in
-// the reference; the never-written zero padding is synthesised instead of
-// stored (rows below lo_p read as 0).
-//   SRCMODE 0: pass 1 builds weight = !flag / data = flag ? 0 : x on the fly
-//              from (srcData, srcFlags) (masked_gaussian_filter,
-//              flagging.py:500-503).
-//   SRCMODE 1: the unfiltered images were already written into rows
-//              [4r, 4r+n) of bufW / bufO (by the transposing copy).
-// Pass 4 divides by float32(d)**4 (host-computed, square-and-multiply as
-// numba does) and writes rows [0,n) of dstW / dstO.
-// grid (ceil(C/BLK), W, 2 images), block BLK
-// ---------------------------------------------------------------------------
-#define CF_U 8
-template <int SRCMODE>
-__global__ void __launch_bounds__(256)
-k_colfilter(float* __restrict__ bufW, float* __restrict__ bufO,
-            const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags,
-            float* __restrict__ dstW, float* __restrict__ dstO,
-            int n, int C, int r, float denom, size_t bws, size_t sws, size_t dws) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    size_t win = blockIdx.y;
-    const int img = blockIdx.z;  // 0 = weight image, 1 = data image
-    float* buf = (img == 0 ? bufW : bufO) + win * bws + c;
-    float* dst = (img == 0 ? dstW : dstO) + win * dws + c;
-    const float* sd = SRCMODE == 0 ? srcData + win * sws + c : nullptr;
-    const uint8_t* sf = SRCMODE == 0 ? srcFlags + win * sws + c : nullptr;
-    const int R2 = 2 * r, R4 = 4 * r;
-    const int P = n + R4;
-    const size_t Cs = (size_t)C;
-
-    auto rd = [&](int j, int p) -> float {
-        // value of padded[j] as seen by pass p (j in [0, P))
-        if (p == 1) {
-            int jj = j - R4;
-            if (jj < 0) return 0.0f;
-            if (SRCMODE == 0) {
-                bool fl = sf[(size_t)jj * Cs] != 0;
-                if (img == 0) return fl ? 0.0f : 1.0f;
-                return fl ? 0.0f : sd[(size_t)jj * Cs];
-            }
-            return buf[(size_t)j * Cs];
-        }
-        if (p == 2 && j < R2) return 0.0f;
-        return buf[(size_t)j * Cs];
-    };
-
-    for (int p = 1; p <= 4; p++) {
-        double s = 0.0;
-        if (p >= 3) {
-            // flagging.py:404-405: pre-add padded[prev_start .. start + 2r)
-            int i = 0;
-            for (; i + CF_U <= R2; i += CF_U) {
-                float v[CF_U];
-#pragma unroll
-                for (int u = 0; u < CF_U; u++) v[u] = rd(i + u, p);
-#pragma unroll
-                for (int u = 0; u < CF_U; u++) s += (double)v[u];
-            }
-            for (; i < R2; i++) s += (double)rd(i, p);
-        }
-        const int start = (p == 1) ? R2 : 0;
-        const int stop = (p == 4) ? n : (p == 3 ? n + R2 : P);
-        const int tail = n + R2;
-        const int mainEnd = min(tail, stop);
-        int i = start;
-        for (; i + CF_U <= mainEnd; i += CF_U) {
-            float lead[CF_U], prev[CF_U], o[CF_U];
-#pragma unroll
-            for (int u = 0; u < CF_U; u++) lead[u] = rd(i + u + R2, p);
-#pragma unroll
-            for (int u = 0; u < CF_U; u++) prev[u] = rd(i + u, p);
-#pragma unroll
-            for (int u = 0; u < CF_U; u++) {
-                s += (double)lead[u];
-                o[u] = (float)s;
-                s -= (double)prev[u];
-            }
-            if (p < 4) {
-#pragma unroll
-                for (int u = 0; u < CF_U; u++) buf[(size_t)(i + u) * Cs] = o[u];
-            } else {
-#pragma unroll
-                for (int u = 0; u < CF_U; u++) dst[(size_t)(i + u) * Cs] = o[u] / denom;
-            }
-        }
-        for (; i < mainEnd; i++) {
-            float lead = rd(i + R2, p);
-            float prev = rd(i, p);
-            s += (double)lead;
-            float o = (float)s;
-            s -= (double)prev;
-            if (p < 4) buf[(size_t)i * Cs] = o;
-            else dst[(size_t)i * Cs] = o / denom;
-        }
-        // flagging.py:412-416 (no leading sample left)
-        for (i = mainEnd; i < stop; i++) {
-            float prev = rd(i, p);
-            float o = (float)s;
-            s -= (double)prev;
-            if (p < 4) buf[(size_t)i * Cs] = o;
-            else dst[(size_t)i * Cs] = o / denom;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// K4b  Single-sweep variant of the box filter for moderate radii: the four
-// passes run as a cascade of causal running sums in ONE pass over the line
-// (HBM traffic: one read and one write per image sample), with each stage's
-// 2r-deep delay line in LDS ([stage][slot][thread], conflict-free).
-//
-// Equivalence with the in-place passes of flagging.py:394-417 (t = causal
-// index, in_p = input stream of pass p, zero where the reference's padded
-// array holds padding or was never written):
-//     s_p += in_p[t];  out_p[t] = f32(s_p);  s_p -= in_p[t - 2r]
-// with in_1 = data (t in [0,n)), in_2 = out_1 (t in [0,n+2r)), in_3 = out_2
-// (t in [0,n+4r)), in_4 = out_3 restricted to t >= 2r (the reference never
-// forms padded_3 below index 0), result y[i] = out_4[i + 4r] / f32(d)**4.
-// Adding / subtracting the synthesised zeros is exact, so every float64
-// value equals the reference's.  Stage p+1 runs one step behind stage p so
-// the four float64 chains of a step are independent.
-// grid (ceil(C/BT), W, 2 images), block BT, dynamic LDS 4 * 2r * BT floats
-// ---------------------------------------------------------------------------
-template <int SRCMODE, bool DIV, bool TOUT>
-__global__ void __launch_bounds__(256)
-k_colfilter_lds(const float* __restrict__ srcW, const float* __restrict__ srcO,
-                const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags,
-                float* __restrict__ dstW, float* __restrict__ dstO,
-                int n, int C, int r, float denom, size_t sws_img, size_t sws, size_t dws) {
-    extern __shared__ float cf_ring[];
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const size_t win = blockIdx.y;
-    const int img = blockIdx.z;
-    const int BT = blockDim.x;
-    const int R2 = 2 * r;
-    const size_t Cs = (size_t)C;
-    const float* src = SRCMODE == 1 ? ((img == 0 ? srcW : srcO) + win * sws_img + c) : nullptr;
-    const float* sd = SRCMODE != 1 ? srcData + win * sws + c : nullptr;
-    const uint8_t* sf = SRCMODE == 0 ? srcFlags + win * sws + c : nullptr;
-    // SRCMODE 2: flags packed four line positions per 32-bit word, [n/4][C]
-    // words (byte k of word q = flag of position 4q + k): one coalesced dword
-    // load per four steps instead of a byte load per step
-    const unsigned* sf4 = SRCMODE == 2 ? reinterpret_cast<const unsigned*>(srcFlags) + win * (sws / 4) + c : nullptr;
-    // TOUT: the output is written TRANSPOSED -- line c becomes row c of an
-    // [C][n] image (n % 4 == 0) -- four consecutive outputs per 16-byte store,
-    // so the frequency-axis stage can consume it without a transpose pass.
-    float* dst = (img == 0 ? dstW : dstO) + win * dws + (TOUT ? (size_t)c * n : (size_t)c);
-    float tacc0 = 0.0f, tacc1 = 0.0f, tacc2 = 0.0f;
-    float* ring = cf_ring + threadIdx.x;            // element (p, slot) at ((p*R2)+slot)*BT
-    for (int k = 0; k < 4 * R2; k++) ring[(size_t)k * BT] = 0.0f;
-
-    auto load = [&](int t) -> float {
-        if (SRCMODE == 0) {
-            bool fl = sf[(size_t)t * Cs] != 0;
-            if (img == 0) return fl ? 0.0f : 1.0f;
-            return fl ? 0.0f : sd[(size_t)t * Cs];
-        }
-        if (SRCMODE == 2) {
-            unsigned wq = sf4[(size_t)(t >> 2) * Cs];
-            bool fl = ((wq >> (8 * (t & 3))) & 0xFFu) != 0;
-            if (img == 0) return fl ? 0.0f : 1.0f;
-            return fl ? 0.0f : sd[(size_t)t * Cs];
-        }
-        return src[(size_t)t * Cs];
-    };
-
-    double s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0;
-    float o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;       // stage outputs of the previous step
-    int slot1 = 0, slot2 = 0, slot3 = 0, slot4 = 0;
-    const int total = n + 4 * r + 3;
-    // Deep prefetch: with the LDS rings capping occupancy at 2 waves / SIMD,
-    // bytes in flight (Little's law against ~2 us of HBM latency) come from
-    // per-thread loads, not from thread count.
-    constexpr int PF = 32;
-    float pre[PF], cur[PF];
-    unsigned prew[PF / 4];   // SRCMODE 2: raw packed-flag words in flight with pre[]
-    // issue the loads of samples [t0, t0 + PF); the values are only consumed one
-    // block later, so the loads stay in flight across a block of arithmetic
-    auto issue = [&](int t0) {
-        if (SRCMODE == 2) {
-#pragma unroll
-            for (int q = 0; q < PF / 4; q++) {
-                int t = t0 + 4 * q;
-                prew[q] = (t < n) ? sf4[(size_t)(t >> 2) * Cs] : 0x01010101u;
-            }
-            if (img == 1) {
-#pragma unroll
-                for (int u = 0; u < PF; u++) {
-                    int t = t0 + u;
-                    pre[u] = (t < n) ? sd[(size_t)t * Cs] : 0.0f;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < PF; u++) {
-                int t = t0 + u;
-                pre[u] = (t < n) ? load(t) : 0.0f;
-            }
-        }
-    };
-    issue(0);
-
-    // One cascade step.  FAST = every stage is inside its steady range
-    // (4r + 3 <= m, m < n): no bounds tests, so the four float64 chains of a
-    // step are straight-line code the scheduler can interleave.
-    // Ring reads are issued one step ahead (R2 >= 2, so the slot read for step
-    // m + 1 differs from the slot written at step m): their LDS latency hides
-    // behind the arithmetic of the current step instead of stalling each stage.
-    float* rp1 = ring;
-    float* rp2 = ring + (size_t)(1 * R2) * BT;
-    float* rp3 = ring + (size_t)(2 * R2) * BT;
-    float* rp4 = ring + (size_t)(3 * R2) * BT;
-    float old1 = 0.0f, old2 = 0.0f, old3 = 0.0f, old4 = 0.0f;   // rings start zeroed
-    auto nextslot = [&](int sl) { return (sl + 1 == R2) ? 0 : sl + 1; };
-
-    auto step = [&](auto fastc, const int m, const float xin) {
-        constexpr bool FAST = decltype(fastc)::value;
-        const bool a4 = FAST || (m - 3 >= 0 && m - 3 < n + 4 * r);
-        const bool a3 = FAST || (m - 2 >= 0 && m - 2 < n + 4 * r);
-        const bool a2 = FAST || (m - 1 >= 0 && m - 1 < n + 4 * r);
-        const bool a1 = FAST || (m < n + R2);
-        const int ns1 = a1 ? nextslot(slot1) : slot1, ns2 = a2 ? nextslot(slot2) : slot2;
-        const int ns3 = a3 ? nextslot(slot3) : slot3, ns4 = a4 ? nextslot(slot4) : slot4;
-        // prefetch next step's trailing samples
-        const float nold1 = rp1[(size_t)ns1 * BT], nold2 = rp2[(size_t)ns2 * BT];
-        const float nold3 = rp3[(size_t)ns3 * BT], nold4 = rp4[(size_t)ns4 * BT];
-        // stage 4 (time t4 = m - 3): input out_3[t4], present for 2r <= t4 < n + 4r
-        if (a4) {
-            const int t = m - 3;
-            float in = (FAST || t >= R2) ? o3 : 0.0f;
-            rp4[(size_t)slot4 * BT] = in;
-            s4 += (double)in;
-            float out = (float)s4;
-            s4 -= (double)old4;
-            int i = t - 4 * r;
-            if (FAST || i >= 0) {
-                float y = DIV ? out / denom : out;
-                if (TOUT) {
-                    const int ph = i & 3;
-                    if (ph == 0) tacc0 = y;
-                    else if (ph == 1) tacc1 = y;
-                    else if (ph == 2) tacc2 = y;
-                    else *reinterpret_cast<float4*>(dst + (i - 3)) = make_float4(tacc0, tacc1, tacc2, y);
-                } else {
-                    dst[(size_t)i * Cs] = y;
-                }
-            }
-        }
-        // stage 3 (t3 = m - 2): input out_2[t3], t3 in [0, n + 4r)
-        if (a3) {
-            float in = o2;
-            rp3[(size_t)slot3 * BT] = in;
-            s3 += (double)in;
-            o3 = (float)s3;
-            s3 -= (double)old3;
-        }
-        // stage 2 (t2 = m - 1): input out_1[t2] for t2 < n + 2r, then drains to n + 4r
-        if (a2) {
-            float in = (FAST || m - 1 < n + R2) ? o1 : 0.0f;
-            rp2[(size_t)slot2 * BT] = in;
-            s2 += (double)in;
-            o2 = (float)s2;
-            s2 -= (double)old2;
-        }
-        // stage 1 (t1 = m): input data[t1] for t1 < n, drains to n + 2r
-        if (a1) {
-            float in = (FAST || m < n) ? xin : 0.0f;
-            rp1[(size_t)slot1 * BT] = in;
-            s1 += (double)in;
-            o1 = (float)s1;
-            s1 -= (double)old1;
-        }
-        // a stage that did not run keeps its pending trailing sample
-        if (a1) { old1 = nold1; slot1 = ns1; }
-        if (a2) { old2 = nold2; slot2 = ns2; }
-        if (a3) { old3 = nold3; slot3 = ns3; }
-        if (a4) { old4 = nold4; slot4 = ns4; }
-    };
-
-    for (int m0 = 0; m0 < total; m0 += PF) {
-        if (SRCMODE == 2) {
-#pragma unroll
-            for (int u = 0; u < PF; u++) {
-                bool fl = ((prew[u >> 2] >> (8 * (u & 3))) & 0xFFu) != 0;
-                cur[u] = (img == 0) ? (fl ? 0.0f : 1.0f) : (fl ? 0.0f : pre[u]);
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < PF; u++) cur[u] = pre[u];
-        }
-        issue(m0 + PF);
-        if (m0 >= 4 * r + 3 && m0 + PF <= n) {
-#pragma unroll
-            for (int u = 0; u < PF; u++) step(std::true_type{}, m0 + u, cur[u]);
-        } else {
-#pragma unroll
-            for (int u = 0; u < PF; u++) step(std::false_type{}, m0 + u, cur[u]);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// K4b'  Single-sweep box filter (K4b) whose INPUT images are stored
-// transposed: line c is row c of an [C][ld] array (so the time-axis stage's TF
-// output feeds the frequency-axis stage without a transpose pass).  Each
-// workgroup (128 lines) stages 32 line positions at a time through an LDS
-// tile: global loads are 128-byte row segments (coalesced along the line),
-// the tile is read back column-wise, one value per thread and step.  The
-// arithmetic is that of K4b.  grid (ceil(C/128), W, 2 images), block 128,
-// dynamic LDS: 4 * 2r * 128 floats (rings) + 32 * 129 floats (tile)
-// ---------------------------------------------------------------------------
-#define CFT_BT 128
-#define CFT_PF 32
-template <bool DIV>
-__global__ void __launch_bounds__(CFT_BT)
-k_colfilter_lds_t(const float* __restrict__ srcW, const float* __restrict__ srcO,
-                  float* __restrict__ dstW, float* __restrict__ dstO,
-                  int n, int C, int ld, int r, float denom, size_t sws_img, size_t dws) {
-    extern __shared__ float cf_ring[];
-    const int tid = threadIdx.x;
-    const int c0 = blockIdx.x * CFT_BT;
-    const int c = c0 + tid;
-    const bool colok = c < C;
-    const size_t win = blockIdx.y;
-    const int img = blockIdx.z;
-    const int R2 = 2 * r;
-    const size_t Cs = (size_t)C;
-    const float* src = (img == 0 ? srcW : srcO) + win * sws_img;
-    float* dst = (img == 0 ? dstW : dstO) + win * dws + (colok ? c : 0);
-    float* ring = cf_ring + tid;                                 // element (p, slot) at ((p*R2)+slot)*BT
-    float* tile = cf_ring + (size_t)4 * R2 * CFT_BT;             // [CFT_PF][CFT_BT + 1]
-    for (int k = 0; k < 4 * R2; k++) ring[(size_t)k * CFT_BT] = 0.0f;
-
-    // staging: element e = j * 128 + tid of a [128 lines][32 positions] patch:
-    // line = e / 32, position = e % 32  ->  lanes 0..31 read 128 contiguous bytes
-    const int s_pos = tid & 31;
-    const int s_line0 = tid >> 5;                                // + 4 j
-    float pre[CFT_PF], cur[CFT_PF];
-    auto issue = [&](int t0) {
-#pragma unroll
-        for (int j = 0; j < CFT_PF; j++) {
-            int line = c0 + 4 * j + s_line0;
-            int t = t0 + s_pos;
-            pre[j] = (line < C && t < n) ? src[(size_t)line * ld + t] : 0.0f;
-        }
-    };
-    // registers -> LDS tile (transposed) -> this thread's 32 samples
-    auto exchange = [&]() {
-        __syncthreads();                                         // previous tile fully consumed
-#pragma unroll
-        for (int j = 0; j < CFT_PF; j++) tile[s_pos * (CFT_BT + 1) + 4 * j + s_line0] = pre[j];
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < CFT_PF; u++) cur[u] = tile[u * (CFT_BT + 1) + tid];
-    };
-
-    double s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0;
-    float o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;
-    int slot1 = 0, slot2 = 0, slot3 = 0, slot4 = 0;
-    float* rp1 = ring;
-    float* rp2 = ring + (size_t)(1 * R2) * CFT_BT;
-    float* rp3 = ring + (size_t)(2 * R2) * CFT_BT;
-    float* rp4 = ring + (size_t)(3 * R2) * CFT_BT;
-    float old1 = 0.0f, old2 = 0.0f, old3 = 0.0f, old4 = 0.0f;
-    auto nextslot = [&](int sl) { return (sl + 1 == R2) ? 0 : sl + 1; };
-    const int total = n + 4 * r + 3;
-
-    auto step = [&](auto fastc, const int m, const float xin) {
-        constexpr bool FAST = decltype(fastc)::value;
-        const bool a4 = FAST || (m - 3 >= 0 && m - 3 < n + 4 * r);
-        const bool a3 = FAST || (m - 2 >= 0 && m - 2 < n + 4 * r);
-        const bool a2 = FAST || (m - 1 >= 0 && m - 1 < n + 4 * r);
-        const bool a1 = FAST || (m < n + R2);
-        const int ns1 = a1 ? nextslot(slot1) : slot1, ns2 = a2 ? nextslot(slot2) : slot2;
-        const int ns3 = a3 ? nextslot(slot3) : slot3, ns4 = a4 ? nextslot(slot4) : slot4;
-        const float nold1 = rp1[(size_t)ns1 * CFT_BT], nold2 = rp2[(size_t)ns2 * CFT_BT];
-        const float nold3 = rp3[(size_t)ns3 * CFT_BT], nold4 = rp4[(size_t)ns4 * CFT_BT];
-        if (a4) {
-            const int t = m - 3;
-            float in = (FAST || t >= R2) ? o3 : 0.0f;
-            rp4[(size_t)slot4 * CFT_BT] = in;
-            s4 += (double)in;
-            float out = (float)s4;
-            s4 -= (double)old4;
-            int i = t - 4 * r;
-            if ((FAST || i >= 0) && colok) dst[(size_t)i * Cs] = DIV ? out / denom : out;
-        }
-        if (a3) {
-            float in = o2;
-            rp3[(size_t)slot3 * CFT_BT] = in;
-            s3 += (double)in;
-            o3 = (float)s3;
-            s3 -= (double)old3;
-        }
-        if (a2) {
-            float in = (FAST || m - 1 < n + R2) ? o1 : 0.0f;
-            rp2[(size_t)slot2 * CFT_BT] = in;
-            s2 += (double)in;
-            o2 = (float)s2;
-            s2 -= (double)old2;
-        }
-        if (a1) {
-            float in = (FAST || m < n) ? xin : 0.0f;
-            rp1[(size_t)slot1 * CFT_BT] = in;
-            s1 += (double)in;
-            o1 = (float)s1;
-            s1 -= (double)old1;
-        }
-        if (a1) { old1 = nold1; slot1 = ns1; }
-        if (a2) { old2 = nold2; slot2 = ns2; }
-        if (a3) { old3 = nold3; slot3 = ns3; }
-        if (a4) { old4 = nold4; slot4 = ns4; }
-    };
-
-    issue(0);
-    for (int m0 = 0; m0 < total; m0 += CFT_PF) {
-        exchange();                 // tile of positions [m0, m0 + 32) -> cur[]
-        issue(m0 + CFT_PF);         // next tile's loads stay in flight during the arithmetic
-        if (m0 >= 4 * r + 3 && m0 + CFT_PF <= n) {
-#pragma unroll
-            for (int u = 0; u < CFT_PF; u++) step(std::true_type{}, m0 + u, cur[u]);
-        } else {
-#pragma unroll
-            for (int u = 0; u < CFT_PF; u++) step(std::false_type{}, m0 + u, cur[u]);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// K4c  "Lane-per-stage" form of the single-sweep box filter for medium radii
-// (the four 2r-deep delay lines of K4b no longer fit LDS at useful occupancy):
-// the four cascade stages of one line run in the four lanes of a quad, every
-// thread owning ONE stage and ONE LDS ring (2r floats), so the same LDS holds
-// four times the threads.  Stage p takes its input from lane p-1's output of
-// the previous step (DPP quad shuffle); the quad's four lanes prefetch four
-// consecutive line positions per load instruction and the stage-0 lane picks
-// them up by DPP broadcast.  Arithmetic per stage is identical to K4b (same
-// causal running sums, same order) -- only the thread that executes a stage
-// differs.  One wave (16 lines) per workgroup; no barriers.
-// grid (ceil(C/16), W, 2 images), block 64, dynamic LDS 2r * 64 floats
-// ---------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ float dpp_quad(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
-}
-// quad_perm(a,b,c,d): lane i of each quad reads lane {a,b,c,d}[i]
-#define QUAD_PERM(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
-
-template <int SRCMODE, bool DIV>
-__global__ void __launch_bounds__(64)
-k_colfilter_lane4(const float* __restrict__ srcW, const float* __restrict__ srcO,
-                  const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags,
-                  float* __restrict__ dstW, float* __restrict__ dstO,
-                  int n, int C, int r, float denom, size_t sws_img, size_t sws, size_t dws) {
-    extern __shared__ float cf_ring[];
-    const int lane = threadIdx.x;
-    const int p = lane & 3;                         // cascade stage of this lane
-    const int c = blockIdx.x * 16 + (lane >> 2);
-    const bool colok = c < C;
-    const int cc = colok ? c : C - 1;               // out-of-range quads compute on a valid column, store nothing
-    const size_t win = blockIdx.y;
-    const int img = blockIdx.z;
-    const int R2 = 2 * r;
-    const size_t Cs = (size_t)C;
-    const float* src = SRCMODE == 1 ? ((img == 0 ? srcW : srcO) + win * sws_img + cc) : nullptr;
-    const float* sd = SRCMODE != 1 ? srcData + win * sws + cc : nullptr;
-    const unsigned* sf4 = SRCMODE == 2 ? reinterpret_cast<const unsigned*>(srcFlags) + win * (sws / 4) + cc : nullptr;
-    float* dst = (img == 0 ? dstW : dstO) + win * dws + cc;
-    float* ring = cf_ring + lane;                   // slot k at ring[k * 64]
-    for (int k = 0; k < R2; k++) ring[k * 64] = 0.0f;
-
-    // per-stage ranges (see K4b): stage p runs for t in [0, tend); its input is
-    // the upstream value for t in [ilo, ihi), zero otherwise
-    const int tend = (p == 0) ? n + R2 : n + 4 * r;
-    const int ilo = (p == 3) ? R2 : 0;
-    const int ihi = (p == 0) ? n : ((p == 1) ? n + R2 : n + 4 * r);
-
-    constexpr int PF = 32;                          // steps per block; each lane prefetches PF/4 positions
-    float pre[PF / 4], cur[PF / 4];
-    unsigned prew[PF / 4];
-    // lane (line, p) loads positions t0 + 4 q + p
-    auto issue = [&](int t0) {
-#pragma unroll
-        for (int q = 0; q < PF / 4; q++) {
-            int t = t0 + 4 * q + p;
-            if (SRCMODE == 2) {
-                prew[q] = (t < n) ? sf4[(size_t)(t >> 2) * Cs] : 0x01010101u;
-                pre[q] = (t < n && img == 1) ? sd[(size_t)t * Cs] : 0.0f;
-            } else {
-                pre[q] = (t < n) ? src[(size_t)t * Cs] : 0.0f;
-            }
-        }
-    };
-    issue(0);
-
-    double s = 0.0;
-    float o_last = 0.0f;                            // this stage's output of the previous step
-    int slot = 0;
-    float old = 0.0f;
-    const int total = n + 4 * r + 3;
-    for (int m0 = 0; m0 < total; m0 += PF) {
-#pragma unroll
-        for (int q = 0; q < PF / 4; q++) {
-            if (SRCMODE == 2) {
-                bool fl = ((prew[q] >> (8 * p)) & 0xFFu) != 0;   // byte p of the word = position 4q + p
-                cur[q] = (img == 0) ? (fl ? 0.0f : 1.0f) : (fl ? 0.0f : pre[q]);
-            } else {
-                cur[q] = pre[q];
-            }
-        }
-        issue(m0 + PF);
-#pragma unroll
-        for (int u = 0; u < PF; u++) {
-            const int m = m0 + u;
-            const int t = m - p;                    // this stage's time index
-            // sample for stage 0: position m was loaded by lane (u & 3) of the quad
-            float xs;
-            if ((u & 3) == 0) xs = dpp_quad<QUAD_PERM(0, 0, 0, 0)>(cur[u >> 2]);
-            else if ((u & 3) == 1) xs = dpp_quad<QUAD_PERM(1, 1, 1, 1)>(cur[u >> 2]);
-            else if ((u & 3) == 2) xs = dpp_quad<QUAD_PERM(2, 2, 2, 2)>(cur[u >> 2]);
-            else xs = dpp_quad<QUAD_PERM(3, 3, 3, 3)>(cur[u >> 2]);
-            // upstream stage's previous output
-            const float up = dpp_quad<QUAD_PERM(0, 0, 1, 2)>(o_last);
-            const bool act = t >= 0 && t < tend;
-            float in = (p == 0) ? xs : up;
-            in = (t >= ilo && t < ihi) ? in : 0.0f;
-            const int ns = (slot + 1 == R2) ? 0 : slot + 1;
-            const float nold = ring[ns * 64];       // next step's trailing sample (R2 >= 2)
-            if (act) {
-                ring[slot * 64] = in;
-                s += (double)in;
-                o_last = (float)s;
-                s -= (double)old;
-                old = nold;
-                slot = ns;
-                if (p == 3) {
-                    const int i = t - 4 * r;
-                    if (i >= 0 && colok) dst[(size_t)i * Cs] = DIV ? o_last / denom : o_last;
-                }
-            }
-        }
-    }
-}
-
-// r == 0 on both axes: weight = !flag, data = flag ? 0 : x (flagging.py:500-503
-// followed by the plain copy of flagging.py:465-466).
-__global__ void k_build_wo(const float* __restrict__ data, const uint8_t* __restrict__ flags,
-                           float* __restrict__ w, float* __restrict__ o, size_t nper,
-                           size_t sws, size_t dws) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nper) return;
-    size_t win = blockIdx.y;
-    bool fl = flags[win * sws + i] != 0;
-    w[win * dws + i] = fl ? 0.0f : 1.0f;
-    o[win * dws + i] = fl ? 0.0f : data[win * sws + i];
-}
-
-__global__ void k_build_wo4(const float* __restrict__ data, const uint8_t* __restrict__ flags,
-                            float* __restrict__ w, float* __restrict__ o, size_t n4per,
-                            size_t sws, size_t dws) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4per) return;
-    size_t win = blockIdx.y;
-    uchar4 f = reinterpret_cast<const uchar4*>(flags + win * sws)[i];
-    float4 d = reinterpret_cast<const float4*>(data + win * sws)[i];
-    reinterpret_cast<float4*>(w + win * dws)[i] =
-        make_float4(f.x ? 0.0f : 1.0f, f.y ? 0.0f : 1.0f, f.z ? 0.0f : 1.0f, f.w ? 0.0f : 1.0f);
-    reinterpret_cast<float4*>(o + win * dws)[i] =
-        make_float4(f.x ? 0.0f : d.x, f.y ? 0.0f : d.y, f.z ? 0.0f : d.z, f.w ? 0.0f : d.w);
-}
-
-// ---------------------------------------------------------------------------
-// K5  masked_gaussian_filter tail (flagging.py:506-513) and the background
-// residual (flagging.py:563-566):  bg = w == 0 ? NaN : o / w;
-//   MODE 0: o <- bg          MODE 1: o <- |data - bg|
-// ---------------------------------------------------------------------------
-template <int MODE>
-__global__ void k_masked_div(const float* __restrict__ w, float* __restrict__ o,
-                             const float* __restrict__ data, size_t nper, size_t ws_wo,
-                             size_t ws_data, float denom, uint8_t* __restrict__ nanflag, int C) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nper) return;
-    size_t win = blockIdx.y;
-    float wv = w[win * ws_wo + i];
-    float ov = o[win * ws_wo + i];
-    if (denom != 0.0f) { wv = wv / denom; ov = ov / denom; }   // deferred flagging.py:419
-    float bg = (wv == 0.0f) ? NAN : ov / wv;
-    // remember which lines (columns) hold a NaN: only those need the
-    // sequential interpolation pass
-    if (MODE == 0 && nanflag && isnan(bg)) nanflag[win * (size_t)C + (i % C)] = 1;
-    if (MODE == 1) bg = fabsf(data[win * ws_data + i] - bg);
-    o[win * ws_wo + i] = bg;
-}
-
-// flags |= resid > median * (MAD_NORMAL * reject)   (flagging.py:567-574);
-// float32 residual compared in float64; NaN compares false.
-// Array layout [L][C] per window; chunk_of[l] gives the chunk of line index l.
-// thr index: TWOD ? (win*G + g) : (c*G + g)   [spectrum layout: column = window]
-template <bool TWOD>
-__global__ void k_reject(const float* __restrict__ resid, uint8_t* __restrict__ flags,
-                         const double* __restrict__ med, const int* __restrict__ chunk_of,
-                         double scale, int L, int C, int G, size_t ws_resid, size_t ws_flags) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)L * C) return;
-    size_t win = blockIdx.y;
-    int l = (int)(i / C), c = (int)(i % C);
-    int g = chunk_of[l];
-    double m = TWOD ? med[win * G + g] : med[(size_t)c * G + g];
-    double thr = m * scale;
-    if ((double)resid[win * ws_resid + i] > thr) flags[win * ws_flags + i] = 1;
-}
-
-// ---------------------------------------------------------------------------
-// K6  _linearly_interpolate_nans1d (flagging.py:307-344) along the line axis
-// of [L][C], one thread per column.  numba typing: grad = (f32 - f32) / int64
-// -> float64; value = f32(f32 + int64 * f64) evaluated in float64.
-// grid (ceil(C/256), W)
-// ---------------------------------------------------------------------------
-__global__ void k_colinterp(float* __restrict__ a, int L, int C, size_t ws,
-                            const uint8_t* __restrict__ nanflag) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    if (nanflag && !nanflag[(size_t)blockIdx.y * C + c]) return;   // no NaN in this line
-    float* x = a + (size_t)blockIdx.y * ws + c;
-    const size_t Cs = (size_t)C;
-    int last = -1;       // index of the last valid sample
-    float lastv = 0.0f;
-    int run = 0;         // start of the current NaN run
-    for (int i = 0; i < L; i++) {
-        float v = x[(size_t)i * Cs];
-        if (isnan(v)) continue;
-        if (run < i) {
-            if (last < 0) {
-                for (int j = run; j < i; j++) x[(size_t)j * Cs] = v;  // extrapolate backwards
-            } else {
-                float diff = v - lastv;
-                double grad = (double)diff / (double)(i - last);
-                for (int j = run; j < i; j++)
-                    x[(size_t)j * Cs] = (float)((double)lastv + (double)(j - last) * grad);
-            }
-        }
-        last = i;
-        lastv = v;
-        run = i + 1;
-    }
-    if (run < L) {
-        float fill = last < 0 ? 0.0f : lastv;  // all NaN -> zeros; else extrapolate forwards
-        for (int j = run; j < L; j++) x[(size_t)j * Cs] = fill;
-    }
-}
-
-// out = a - b  (flagging.py:950, 962)
-__global__ void k_sub(const float* __restrict__ a, const float* __restrict__ b,
-                      float* __restrict__ out, size_t nper, size_t ws_a, size_t ws_b,
-                      size_t ws_o) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nper) return;
-    size_t win = blockIdx.y;
-    out[win * ws_o + i] = a[win * ws_a + i] - b[win * ws_b + i];
-}
-
-__global__ void k_or(uint8_t* __restrict__ a, const uint8_t* __restrict__ b, size_t nper,
-                     size_t ws_a, size_t ws_b) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nper) return;
-    size_t win = blockIdx.y;
-    if (b[win * ws_b + i]) a[win * ws_a + i] = 1;
-}
-
-__global__ void k_copy_u8(const uint8_t* __restrict__ a, uint8_t* __restrict__ b, size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) b[i] = a[i];
-}
-
-// flags[w][t][f] |= spec[f][w]   (flagging.py:954); spec in spectrum layout
-__global__ void k_or_spec(uint8_t* __restrict__ flags, const uint8_t* __restrict__ spec, int T,
-                          int Fa, int Wn) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)T * Fa) return;
-    size_t win = blockIdx.y;
-    int f = (int)(i % Fa);
-    if (spec[(size_t)f * Wn + win]) flags[win * (size_t)T * Fa + i] = 1;
-}
-
-// ---------------------------------------------------------------------------
-// K7  _sum_threshold1d + _convolve_flags (flagging.py:582-681) along the line
-// axis of [L][C]: one thread per (column, chunk) streams down its padded line
-// ONCE, running all windows as a cascade: stage j ingests position i (clamp
-// with the flags of stages < j, float64 sequential prefix sum), forms the
-// rolling sum S_k = cum[k+w] - cum[k] for k = i + 1 - w from a ring of the
-// last w prefix values, thresholds +S and -S against thr0 / rho^log2(w), and
-// dilates hits over w samples; stage j+1 runs w_j - 1 positions behind so
-// that its clamp sees exactly the flags the reference's window loop would
-// (flagging.py:638-674, window order as given).  Every float64 value is
-// produced by the same operations in the same order as the reference.
-// Input flags are used only in the MAD (flagging.py:622), never OR-ed in.
-//
-// Dynamic variant: arbitrary windows; prefix rings and the position ring of
-// accumulated (pos,neg) bits live in a global scratch laid out
-// [slot][thread] (coalesced).
-// grid (ceil(C/BLK), G, W), block BLK
-// ---------------------------------------------------------------------------
-struct StWin {
-    int nw;
-    int w[TRI_MAX_WINDOWS];
-    double tf[TRI_MAX_WINDOWS];     // rho ** log2(w)           (host libm, flagging.py:641)
-    double scale[TRI_MAX_WINDOWS];  // (double)(float)(1.0 / w) (flagging.py:664)
-    int ringoff[TRI_MAX_WINDOWS];   // slot offset of stage j's prefix ring
-    int ringtot;                    // sum of w
-    int delay[TRI_MAX_WINDOWS + 1]; // D_j = sum_{j'<j} (w_j' - 1)
-    int acccap;                     // >= D_nw + 1
-    int maxw;
-};
-
-__global__ void __launch_bounds__(256)
-k_colst_dyn(const float* __restrict__ data, const double* __restrict__ med,
-            uint8_t* __restrict__ out, double* __restrict__ ringbuf,
-            uint8_t* __restrict__ accbuf, const int64_t* __restrict__ chunk_ends, StWin sw,
-            double thr_scale, int L, int C, int G, size_t ws_data, size_t ws_out) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    int g = blockIdx.y;
-    size_t win = blockIdx.z;
-    int c0 = (int)chunk_ends[g], c1 = (int)chunk_ends[g + 1];
-    if (c1 <= c0) return;
-    // thread-private scratch, [slot][thread]
-    size_t nthreads = (size_t)gridDim.z * G * C;
-    size_t tidg = (win * G + g) * (size_t)C + c;
-    double* ring = ringbuf + tidg;
-    uint8_t* acc = accbuf + tidg;
-    const float* x = data + win * ws_data + c;
-    uint8_t* o = out + win * ws_out + c;
-    const size_t Cs = (size_t)C;
-
-    // flagging.py:622-628
-    float mad = (float)med[(win * (size_t)C + c) * G + g];
-    float thr0 = isnan(mad) ? INFINITY : (float)((double)mad * thr_scale);
-    // flagging.py:630-633 (slicing clamps to the axis length)
-    int p0 = max(c0 - sw.maxw + 1, 0);
-    int p1 = min(c1 + sw.maxw - 1, L);
-    int Lp = p1 - p0;
-
-    const int nw = sw.nw;
-    double thr[TRI_MAX_WINDOWS], cumlast[TRI_MAX_WINDOWS];
-    int sincep[TRI_MAX_WINDOWS], sincen[TRI_MAX_WINDOWS];
-    for (int j = 0; j < nw; j++) {
-        thr[j] = (double)thr0 / sw.tf[j];
-        cumlast[j] = 0.0;
-        sincep[j] = sincen[j] = 1 << 30;
-        ring[(size_t)sw.ringoff[j] * nthreads] = 0.0;  // cum[0] = 0 in slot 0
-    }
-    for (int s = 0; s < sw.acccap; s++) acc[(size_t)s * nthreads] = 0;
-
-    const int total = Lp + sw.delay[nw];
-    for (int n = 0; n < total; n++) {
-        for (int j = 0; j < nw; j++) {
-            const int w = sw.w[j];
-            int i = n - sw.delay[j];      // ingest position
-            if (i < 0) continue;
-            int e = i + 1 - w;            // emit position
-            if (e >= Lp) continue;
-            bool hp = false, hn = false;
-            if (i < Lp) {
-                uint8_t a = acc[(size_t)(i % sw.acccap) * nthreads];
-                float xf = x[(size_t)(p0 + i) * Cs];
-                double clamped = (double)xf;
-                double limit = thr[j];
-                if ((a & 1) && clamped > limit) clamped = limit;
-                else if ((a & 2) && clamped < -limit) clamped = -limit;
-                double cumnew = cumlast[j] + clamped;
-                cumlast[j] = cumnew;
-                size_t slot = (size_t)(sw.ringoff[j] + ((i + 1) % w)) * nthreads;
-                if (e >= 0) {
-                    double S = cumnew - ring[slot];
-                    hp = S * sw.scale[j] > limit;
-                    hn = S * (-sw.scale[j]) > limit;
-                }
-                ring[slot] = cumnew;
-            }
-            if (e >= 0) {
-                sincep[j] = hp ? 0 : min(sincep[j] + 1, 1 << 30);
-                sincen[j] = hn ? 0 : min(sincen[j] + 1, 1 << 30);
-                uint8_t add = (sincep[j] < w ? 1 : 0) | (sincen[j] < w ? 2 : 0);
-                if (add) acc[(size_t)(e % sw.acccap) * nthreads] |= add;
-            }
-        }
-        int ef = n - sw.delay[nw];        // position final after the last stage
-        if (ef >= 0 && ef < Lp) {
-            size_t aslot = (size_t)(ef % sw.acccap) * nthreads;
-            uint8_t a = acc[aslot];
-            acc[aslot] = 0;               // recycle the slot
-            int pos = p0 + ef;
-            if (pos >= c0 && pos < c1) o[(size_t)pos * Cs] = a ? 1 : 0;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// K7b  Register-resident SumThreshold cascade for power-of-two windows
-// {W0,W1,W2,W3} with W3 <= 8 (the library default and every shipped strategy's
-// time axis: 1,2,4,8).  Same arithmetic as k_colst_dyn, but
-//   * the prefix rings (w doubles per stage), the 8-deep sample ring and the
-//     hit / input-flag histories (bit shift registers) live in VGPRs: the tick
-//     loop is unrolled by 8 so that every ring index is a compile-time
-//     constant;
-//   * stage j+1 runs w_j positions behind stage j (one more than necessary),
-//     so the flag hand-off crosses a tick boundary and the four stages of one
-//     tick are independent instruction streams;
-//   * for a power-of-two window, S * f32(1/w) > thr  <=>  S > thr * w exactly
-//     (both sides scale by 2^k; S is a multiple of 2^-203 or larger, far above
-//     the underflow range), so the threshold tests need no multiply.
-// One thread per (column, chunk); HBM traffic = 4 B in + 1 B out per sample.
-// grid (ceil(C/BLK), G, W), block BLK
-// ---------------------------------------------------------------------------
-struct StFusedArgs {
-    double tf[4];   // rho ** log2(w)
-};
-
-#ifndef ST_WAVES
-#define ST_WAVES 2
-#endif
-template <int W0, int W1, int W2, int W3>
-__global__ void __launch_bounds__(256, ST_WAVES)
-k_colst_fused(const float* __restrict__ data, const double* __restrict__ med,
-              uint8_t* __restrict__ out, const int64_t* __restrict__ chunk_ends,
-              StFusedArgs fa, double thr_scale, int L, int C, int G, size_t ws_data,
-              size_t ws_out) {
-    constexpr int W[4] = {W0, W1, W2, W3};
-    constexpr int D[4] = {0, W0, W0 + W1, W0 + W1 + W2};   // ingest delay of stage j
-    constexpr int DOUT = W0 + W1 + W2 + W3 - 1;             // final flags lag the head by this
-    constexpr int MAXW = W3;
-    constexpr int UN = 16;                                   // ticks per unrolled block
-    static_assert(W0 <= W1 && W1 <= W2 && W2 <= W3 && W3 <= 8, "windows must be sorted, <= 8");
-    static_assert((W0 & (W0 - 1)) == 0 && (W1 & (W1 - 1)) == 0 && (W2 & (W2 - 1)) == 0 &&
-                  (W3 & (W3 - 1)) == 0, "power-of-two windows");
-    static_assert(W0 + W1 + W2 <= 7, "sample ring is 8 deep");
-    static_assert(DOUT < UN, "flag ring is 16 deep");
-
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const int g = blockIdx.y;
-    const size_t win = blockIdx.z;
-    const int c0 = (int)chunk_ends[g], c1 = (int)chunk_ends[g + 1];
-    if (c1 <= c0) return;
-    const float* x = data + win * ws_data + c;
-    uint8_t* o = out + win * ws_out + c;
-    const size_t Cs = (size_t)C;
-
-    float mad = (float)med[(win * (size_t)C + c) * G + g];
-    float thr0 = isnan(mad) ? INFINITY : (float)((double)mad * thr_scale);
-    const int p0 = max(c0 - MAXW + 1, 0);
-    const int p1 = min(c1 + MAXW - 1, L);
-    const int Lp = p1 - p0;
-    const int o0 = c0 - p0, o1 = c1 - p0;   // output interior in padded coordinates
-    x += (size_t)p0 * Cs;
-    o += (size_t)p0 * Cs;
-
-    // thr = f64(thr0) / rho^log2(w) (flagging.py:643); T = thr * w (exact);
-    // lim = largest float32 <= thr, so that for a float32 sample xf
-    //   (double)xf > thr  <=>  xf > lim     and    (double)xf < -thr  <=>  xf < -lim
-    double thr[4], T[4];
-    float lim[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        thr[j] = (double)thr0 / fa.tf[j];
-        T[j] = thr[j] * (double)W[j];
-        float l = (float)thr[j];
-        if ((double)l > thr[j]) {   // rounded up: step to the next float32 below
-            unsigned b = __float_as_uint(l);
-            b = (l > 0.0f) ? b - 1u : ((l < 0.0f) ? b + 1u : 0x80000001u);
-            l = __uint_as_float(b);
-        }
-        lim[j] = l;
-    }
-    double cumlast[4] = {0.0, 0.0, 0.0, 0.0};
-    double r0[W0], r1[W1], r2[W2], r3[W3];
-#pragma unroll
-    for (int k = 0; k < W0; k++) r0[k] = 0.0;
-#pragma unroll
-    for (int k = 0; k < W1; k++) r1[k] = 0.0;
-#pragma unroll
-    for (int k = 0; k < W2; k++) r2[k] = 0.0;
-#pragma unroll
-    for (int k = 0; k < W3; k++) r3[k] = 0.0;
-    // tick of the last positive / negative hit of stage j (far past: none in reach)
-    int sp[4] = {-64, -64, -64, -64}, sn[4] = {-64, -64, -64, -64};
-    // accumulated flags by position (mod 16): stage j ORs its dilated hits in,
-    // stage j+1 reads them for its clamp, the last stage's position is output
-    unsigned accP[UN], accN[UN];
-#pragma unroll
-    for (int k = 0; k < UN; k++) { accP[k] = 0; accN[k] = 0; }
-    float xf[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) xf[k] = 0.0f;
-
-    const int nticks = Lp + DOUT;
-    float cur[UN];
-#pragma unroll
-    for (int u = 0; u < UN; u++) cur[u] = (u < Lp) ? x[(size_t)u * Cs] : 0.0f;
-
-    auto block = [&](auto fastc, const int base) {
-        constexpr bool fast = decltype(fastc)::value;
-#pragma unroll
-        for (int PH = 0; PH < UN; PH++) {
-            const int n = base + PH;
-            xf[PH & 7] = cur[PH];
-            // rolling prefetch: the slot just consumed is refilled 16 ticks ahead
-            cur[PH] = (n + UN < Lp) ? x[(size_t)(n + UN) * Cs] : 0.0f;
-            // stages in reverse order: stage j reads the flags stage j-1 wrote
-            // at the previous tick
-#pragma unroll
-            for (int j = 3; j >= 0; j--) {
-#ifdef ST_EXP_STAGES
-                if (j >= ST_EXP_STAGES) continue;
-#endif
-                const int w = W[j];
-                const int i = n - D[j];        // ingest position
-                const int e = i + 1 - w;       // emit position
-                const bool ing = fast || (i >= 0 && i < Lp);
-                const bool emi = fast || (e >= 0 && e < Lp);
-                bool hp = false, hn = false;
-                if (ing) {
-                    const float xs = xf[(PH - D[j]) & 7];
-                    double cl = (double)xs;
-                    if (j > 0) {
-                        const bool cp = (accP[(PH - D[j]) & (UN - 1)] != 0) && (xs > lim[j]);
-                        const bool cn = !cp && (accN[(PH - D[j]) & (UN - 1)] != 0) && (xs < -lim[j]);
-                        cl = cp ? thr[j] : (cn ? -thr[j] : cl);
-                    }
-                    const double cum = cumlast[j] + cl;
-                    cumlast[j] = cum;
-                    const int slot = (PH - D[j] + 1) & (w - 1);
-                    double old;
-                    if (j == 0) { old = r0[slot & (W0 - 1)]; r0[slot & (W0 - 1)] = cum; }
-                    else if (j == 1) { old = r1[slot & (W1 - 1)]; r1[slot & (W1 - 1)] = cum; }
-                    else if (j == 2) { old = r2[slot & (W2 - 1)]; r2[slot & (W2 - 1)] = cum; }
-                    else { old = r3[slot & (W3 - 1)]; r3[slot & (W3 - 1)] = cum; }
-                    const double S = cum - old;
-                    const bool valid = fast || e >= 0;
-                    hp = valid && (S > T[j]);
-                    hn = valid && (S < -T[j]);
-                }
-                if (emi) {
-                    bool ap, an;
-                    if (w == 1) { ap = hp; an = hn; }
-                    else {
-                        sp[j] = hp ? n : sp[j];      // tick of the last hit
-                        sn[j] = hn ? n : sn[j];
-                        ap = sp[j] > n - w;
-                        an = sn[j] > n - w;
-                    }
-                    const int es = (PH - D[j] + 1 - w) & (UN - 1);
-                    accP[es] = ap ? 1u : accP[es];
-                    accN[es] = an ? 1u : accN[es];
-                }
-            }
-            const int ef = n - DOUT;
-            const int fs = (PH - DOUT) & (UN - 1);
-            if (fast || (ef >= o0 && ef < o1)) o[(size_t)ef * Cs] = (uint8_t)(accP[fs] | accN[fs]);
-            accP[fs] = 0;
-            accN[fs] = 0;
-        }
-    };
-
-    for (int base = 0; base < nticks; base += UN) {
-        const bool fast = base >= UN && base + UN - 1 < Lp && base - DOUT >= o0 && base + UN - 1 - DOUT < o1;
-        if (fast) block(std::true_type{}, base);
-        else block(std::false_type{}, base);
-    }
-}
-
-// ---------------------------------------------------------------------------
-// K8  _combine_flags + _unaverage_freq (flagging.py:784-918), TF layout.
-// comb[t][fa] = any over t' in [t - e/2, t - e/2 + e) of (spec|time|freq).
-// ---------------------------------------------------------------------------
-__global__ void k_combine(const uint8_t* __restrict__ spec, const uint8_t* __restrict__ tflags,
-                          const uint8_t* __restrict__ fflags, uint8_t* __restrict__ comb, int T,
-                          int Fa, int Wn, int lo, int hi) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)T * Fa) return;
-    size_t win = blockIdx.y;
-    int t = (int)(i / Fa), f = (int)(i % Fa);
-    size_t base = win * (size_t)T * Fa;
-    int t0 = max(t + lo, 0), t1 = min(t + hi, T);
-    uint8_t v = 0;
-    if (t1 > t0) {
-        if (spec[(size_t)f * Wn + win]) v = 1;
-        for (int tt = t0; tt < t1 && !v; tt++) {
-            size_t a = base + (size_t)tt * Fa + f;
-            v = (tflags[a] | fflags[a]) ? 1 : 0;
-        }
-    }
-    comb[base + i] = v;
-}
-
-// dil[t][f] = any comb[t][f'/avg] for f' in [f - e/2, f - e/2 + e) clamped;
-// per-row and per-column counts of dil (flagging.py:896-908).
-// grid (ceil(F/256), T, W), block 256
-__global__ void k_unaverage(const uint8_t* __restrict__ comb, uint8_t* __restrict__ dil,
-                            int* __restrict__ rowcnt, int* __restrict__ colcnt, int T, int Fa,
-                            int F, int avg, int lo, int hi) {
-    int f = blockIdx.x * blockDim.x + threadIdx.x;
-    int t = blockIdx.y;
-    size_t win = blockIdx.z;
-    int v = 0;
-    if (f < F) {
-        int f0 = max(f + lo, 0), f1 = min(f + hi, F);
-        const uint8_t* row = comb + win * (size_t)T * Fa + (size_t)t * Fa;
-        for (int ff = f0; ff < f1 && !v; ff++) v = row[ff / avg] ? 1 : 0;
-        dil[win * (size_t)T * F + (size_t)t * F + f] = (uint8_t)v;
-        if (v) atomicAdd(&colcnt[win * (size_t)F + f], 1);
-    }
-    // row count: wave ballot + one atomic per wave
-    unsigned long long b = __ballot(v);
-    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&rowcnt[win * (size_t)T + t], __popcll(b));
-}
-
-// out = dil | row rule | column rule | isnan(vis); iter |= out
-// (flagging.py:910-918, 777-781, 1193)
-template <int VD>
-__global__ void k_final(const uint8_t* __restrict__ dil, const int* __restrict__ rowcnt,
-                        const int* __restrict__ colcnt, const void* __restrict__ vis,
-                        uint8_t* __restrict__ out, uint8_t* __restrict__ iter, int T, int F,
-                        double row_limit, double col_limit, int update_iter) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)T * F) return;
-    size_t win = blockIdx.y;
-    int t = (int)(i / F), f = (int)(i % F);
-    size_t a = win * (size_t)T * F + i;
-    bool v = dil[a] != 0;
-    v = v || ((double)rowcnt[win * (size_t)T + t] > row_limit);
-    v = v || ((double)colcnt[win * (size_t)F + f] > col_limit);
-    v = v || load_isnan<VD>(vis, a);
-    out[a] = v ? 1 : 0;
-    if (update_iter && v) iter[a] = 1;
-}
-
-// ---------------------------------------------------------------------------
-// Vectorised (16 bytes of flags / 4 floats per thread) forms of the
-// elementwise kernels above, used when the row lengths are multiples of 16
-// (every production shape); the scalar kernels remain the general fallback.
-// Flags are 0/1 bytes, so byte-wise OR is a plain bitwise OR of the words.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ uint4 or4(uint4 a, uint4 b) { return make_uint4(a.x | b.x, a.y | b.y, a.z | b.z, a.w | b.w); }
-// per byte: x != 0 ? 1 : 0 (no cross-byte carries)
-__device__ __forceinline__ unsigned nz_bytes(unsigned x) {
-    unsigned t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
-    return ((t | x) & 0x80808080u) >> 7;
-}
-
-template <int VD>
-__global__ void k_prepare4(const void* __restrict__ vis, const uint8_t* __restrict__ iflags,
-                           float* __restrict__ data, uint8_t* __restrict__ flags, size_t n4) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // group of 4 samples, flat over the batch
-    if (i >= n4) return;
-    uchar4 f = reinterpret_cast<const uchar4*>(iflags)[i];
-    float a[4];
-    if (VD == TRI_VIS_C64) {
-        float4 z0 = reinterpret_cast<const float4*>(vis)[2 * i];
-        float4 z1 = reinterpret_cast<const float4*>(vis)[2 * i + 1];
-        a[0] = tri_hypotf(z0.x, z0.y); a[1] = tri_hypotf(z0.z, z0.w);
-        a[2] = tri_hypotf(z1.x, z1.y); a[3] = tri_hypotf(z1.z, z1.w);
-    } else {
-        float4 z = reinterpret_cast<const float4*>(vis)[i];
-        a[0] = fabsf(z.x); a[1] = fabsf(z.y); a[2] = fabsf(z.z); a[3] = fabsf(z.w);
-    }
-    unsigned char fl[4] = {f.x, f.y, f.z, f.w};
-    float o[4];
-    unsigned char of[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        bool bad = fl[k] != 0 || isnan(a[k]);
-        // factor 1: sum = 0 + a, count 1, a / 1.0f = a (flagging.py:858-870)
-        o[k] = bad ? 0.0f : (0.0f + a[k]) / 1.0f;
-        of[k] = bad ? 1 : 0;
-    }
-    reinterpret_cast<float4*>(data)[i] = make_float4(o[0], o[1], o[2], o[3]);
-    reinterpret_cast<uchar4*>(flags)[i] = make_uchar4(of[0], of[1], of[2], of[3]);
-}
-
-// OP 0: b = a   OP 1: b |= a   OP 2: b = (a != 0)     (16 bytes per thread)
-template <int OP>
-__global__ void k_u8_op16(const uint8_t* __restrict__ a, uint8_t* __restrict__ b, size_t n16per,
-                          size_t ws_a, size_t ws_b) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n16per) return;
-    size_t win = blockIdx.y;
-    uint4 va = reinterpret_cast<const uint4*>(a + win * ws_a)[i];
-    uint4* pb = reinterpret_cast<uint4*>(b + win * ws_b) + i;
-    if (OP == 0) *pb = va;
-    else if (OP == 1) *pb = or4(*pb, va);
-    else *pb = make_uint4(nz_bytes(va.x), nz_bytes(va.y), nz_bytes(va.z), nz_bytes(va.w));
-}
-
-// spectrum flags [Fa][Wn] -> rows [Wn][Fa] (tiny), so that the per-window
-// kernels below can read 16 channels at a time
-__global__ void k_spec_rows(const uint8_t* __restrict__ spec, uint8_t* __restrict__ rows, int Fa, int Wn) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)Fa * Wn) return;
-    int w = (int)(i / Fa), f = (int)(i % Fa);
-    rows[i] = spec[(size_t)f * Wn + w];
-}
-
-// flags[w][t][f..f+15] |= spec_rows[w][f..f+15]
-__global__ void k_or_spec16(uint8_t* __restrict__ flags, const uint8_t* __restrict__ spec_rows, int T, int Fa16) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)T * Fa16) return;
-    size_t win = blockIdx.y;
-    int f16 = (int)(i % Fa16);
-    uint4 sp = reinterpret_cast<const uint4*>(spec_rows + win * (size_t)Fa16 * 16)[f16];
-    uint4* pf = reinterpret_cast<uint4*>(flags + win * (size_t)T * Fa16 * 16) + i;
-    *pf = or4(*pf, sp);
-}
-
-// _combine_flags (flagging.py:784-816), 16 channels per thread
-__global__ void k_combine16(const uint8_t* __restrict__ spec_rows, const uint8_t* __restrict__ tflags,
-                            const uint8_t* __restrict__ fflags, uint8_t* __restrict__ comb, int T,
-                            int Fa16, int lo, int hi) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)T * Fa16) return;
-    size_t win = blockIdx.y;
-    int t = (int)(i / Fa16), f16 = (int)(i % Fa16);
-    size_t base = win * (size_t)T * Fa16;
-    int t0 = max(t + lo, 0), t1 = min(t + hi, T);
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (t1 > t0) {
-        v = reinterpret_cast<const uint4*>(spec_rows + win * (size_t)Fa16 * 16)[f16];
-        const uint4* tp = reinterpret_cast<const uint4*>(tflags) + base;
-        const uint4* fp = reinterpret_cast<const uint4*>(fflags) + base;
-        for (int tt = t0; tt < t1; tt++) {
-            size_t a = (size_t)tt * Fa16 + f16;
-            v = or4(v, or4(tp[a], fp[a]));
-        }
-    }
-    reinterpret_cast<uint4*>(comb)[base + i] = v;
-}
-
-// _unaverage_freq (flagging.py:896-908) for average_freq == 1, frequency
-// dilation over [f + LO, f + LO + E), 16 channels per thread; row counts by
-// popcount + one atomic per wave; column counts by k_colcount.
-// grid (ceil(F16/64), T, W), block 64
-template <int LO, int E>
-__global__ void k_unaverage16(const uint8_t* __restrict__ comb, uint8_t* __restrict__ dil,
-                              int* __restrict__ rowcnt, int T, int F16) {
-    int f16 = blockIdx.x * blockDim.x + threadIdx.x;
-    int t = blockIdx.y;
-    size_t win = blockIdx.z;
-    int cnt = 0;
-    if (f16 < F16) {
-        const uint4* row = reinterpret_cast<const uint4*>(comb) + (win * (size_t)T + t) * F16;
-        uint4 z = make_uint4(0, 0, 0, 0);
-        uint4 p = f16 > 0 ? row[f16 - 1] : z;
-        uint4 c = row[f16];
-        uint4 n = f16 + 1 < F16 ? row[f16 + 1] : z;
-        unsigned w[12] = {p.x, p.y, p.z, p.w, c.x, c.y, c.z, c.w, n.x, n.y, n.z, n.w};
-        unsigned o[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            unsigned v = 0;
-#pragma unroll
-            for (int sft = LO; sft < LO + E; sft++) {
-                const int idx = 16 + k + sft;   // byte index into the 48-byte window
-                v |= (w[idx >> 2] >> (8 * (idx & 3))) & 0xFFu;
-            }
-            o[k >> 2] |= (v & 1u) << (8 * (k & 3));
-        }
-        reinterpret_cast<uint4*>(dil)[(win * (size_t)T + t) * F16 + f16] = make_uint4(o[0], o[1], o[2], o[3]);
-        cnt = __popc(o[0]) + __popc(o[1]) + __popc(o[2]) + __popc(o[3]);
-    }
-    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
-    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&rowcnt[win * (size_t)T + t], cnt);
-}
-
-// column counts of a [T][F] 0/1 byte image: one thread per 4 columns
-// grid (ceil(F4/256), W)
-__global__ void k_colcount(const uint8_t* __restrict__ dil, int* __restrict__ colcnt, int T, int F4) {
-    int f4 = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f4 >= F4) return;
-    size_t win = blockIdx.y;
-    const unsigned* p = reinterpret_cast<const unsigned*>(dil) + win * (size_t)T * F4 + f4;
-    unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-    int t = 0;
-    for (; t + 8 <= T; t += 8) {
-        unsigned v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = p[(size_t)(t + u) * F4];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            c0 += v[u] & 0xFFu; c1 += (v[u] >> 8) & 0xFFu; c2 += (v[u] >> 16) & 0xFFu; c3 += v[u] >> 24;
-        }
-    }
-    for (; t < T; t++) {
-        unsigned v = p[(size_t)t * F4];
-        c0 += v & 0xFFu; c1 += (v >> 8) & 0xFFu; c2 += (v >> 16) & 0xFFu; c3 += v >> 24;
-    }
-    reinterpret_cast<int4*>(colcnt)[win * (size_t)F4 + f4] = make_int4((int)c0, (int)c1, (int)c2, (int)c3);
-}
-
-// k_final, 16 samples per thread
-template <int VD>
-__global__ void k_final16(const uint8_t* __restrict__ dil, const int* __restrict__ rowcnt,
-                          const int* __restrict__ colcnt, const void* __restrict__ vis,
-                          uint8_t* __restrict__ out, uint8_t* __restrict__ iter, int T, int F16,
-                          double row_limit, double col_limit, int update_iter) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)T * F16) return;
-    size_t win = blockIdx.y;
-    int t = (int)(i / F16), f16 = (int)(i % F16);
-    size_t a16 = win * (size_t)T * F16 + i;
-    uint4 d = reinterpret_cast<const uint4*>(dil)[a16];
-    unsigned dw[4] = {d.x, d.y, d.z, d.w};
-    bool rowall = (double)rowcnt[win * (size_t)T + t] > row_limit;
-    const int4* cc = reinterpret_cast<const int4*>(colcnt + win * (size_t)F16 * 16) + (size_t)f16 * 4;
-    unsigned o[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        int4 c4 = cc[q];
-        int cv[4] = {c4.x, c4.y, c4.z, c4.w};
-        unsigned nanb = 0;
-        if (VD == TRI_VIS_C64) {
-            const float4* vp = reinterpret_cast<const float4*>(vis) + (a16 * 16 + q * 4) / 2;
-            float4 z0 = vp[0], z1 = vp[1];
-            nanb = ((isnan(z0.x) || isnan(z0.y)) ? 1u : 0u) | ((isnan(z0.z) || isnan(z0.w)) ? 0x100u : 0u) |
-                   ((isnan(z1.x) || isnan(z1.y)) ? 0x10000u : 0u) | ((isnan(z1.z) || isnan(z1.w)) ? 0x1000000u : 0u);
-        } else {
-            float4 z = reinterpret_cast<const float4*>(vis)[(a16 * 16 + q * 4) / 4];
-            nanb = (isnan(z.x) ? 1u : 0u) | (isnan(z.y) ? 0x100u : 0u) | (isnan(z.z) ? 0x10000u : 0u) |
-                   (isnan(z.w) ? 0x1000000u : 0u);
-        }
-        unsigned colb = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) colb |= ((double)cv[k] > col_limit ? 1u : 0u) << (8 * k);
-        o[q] = rowall ? 0x01010101u : (dw[q] | colb | nanb);
-    }
-    uint4 ov = make_uint4(o[0], o[1], o[2], o[3]);
-    reinterpret_cast<uint4*>(out)[a16] = ov;
-    if (update_iter) {
-        uint4* ip = reinterpret_cast<uint4*>(iter) + a16;
-        *ip = or4(*ip, ov);
-    }
-}
-
-template <int MODE>
-__global__ void k_masked_div4(const float* __restrict__ w, float* __restrict__ o,
-                              const float* __restrict__ data, size_t n4per, size_t ws_wo, size_t ws_data,
-                              float denom, uint8_t* __restrict__ nanflag, int C) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4per) return;
-    size_t win = blockIdx.y;
-    float4 wv = reinterpret_cast<const float4*>(w + win * ws_wo)[i];
-    float4* po = reinterpret_cast<float4*>(o + win * ws_wo) + i;
-    float4 ov = *po;
-    if (denom != 0.0f) {   // deferred flagging.py:419
-        wv = make_float4(wv.x / denom, wv.y / denom, wv.z / denom, wv.w / denom);
-        ov = make_float4(ov.x / denom, ov.y / denom, ov.z / denom, ov.w / denom);
-    }
-    float bg[4] = {(wv.x == 0.0f) ? NAN : ov.x / wv.x, (wv.y == 0.0f) ? NAN : ov.y / wv.y,
-                   (wv.z == 0.0f) ? NAN : ov.z / wv.z, (wv.w == 0.0f) ? NAN : ov.w / wv.w};
-    if (MODE == 0 && nanflag) {
-        int cb = (int)((i * 4) % C);   // C % 4 == 0: the four samples are columns cb .. cb + 3
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (isnan(bg[k])) nanflag[win * (size_t)C + cb + k] = 1;
-    }
-    if (MODE == 1) {
-        float4 dv = reinterpret_cast<const float4*>(data + win * ws_data)[i];
-        bg[0] = fabsf(dv.x - bg[0]); bg[1] = fabsf(dv.y - bg[1]);
-        bg[2] = fabsf(dv.z - bg[2]); bg[3] = fabsf(dv.w - bg[3]);
-    }
-    *po = make_float4(bg[0], bg[1], bg[2], bg[3]);
-}
-
-__global__ void k_sub4(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
-                       size_t n4per, size_t ws_a, size_t ws_b, size_t ws_o) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4per) return;
-    size_t win = blockIdx.y;
-    float4 x = reinterpret_cast<const float4*>(a + win * ws_a)[i];
-    float4 y = reinterpret_cast<const float4*>(b + win * ws_b)[i];
-    reinterpret_cast<float4*>(out + win * ws_o)[i] = make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w);
-}
-
-// k_reject<true>, 4 samples per thread (C % 4 == 0 keeps a group in one line)
-__global__ void k_reject4(const float* __restrict__ resid, uint8_t* __restrict__ flags,
-                          const double* __restrict__ med, const int* __restrict__ chunk_of,
-                          double scale, int C4, int G, size_t n4per, size_t ws_resid, size_t ws_flags) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4per) return;
-    size_t win = blockIdx.y;
-    int l = (int)(i / C4);
-    double thr = med[win * G + chunk_of[l]] * scale;
-    float4 rv = reinterpret_cast<const float4*>(resid + win * ws_resid)[i];
-    uchar4* pf = reinterpret_cast<uchar4*>(flags + win * ws_flags) + i;
-    uchar4 f = *pf;
-    if ((double)rv.x > thr) f.x = 1;
-    if ((double)rv.y > thr) f.y = 1;
-    if ((double)rv.z > thr) f.z = 1;
-    if ((double)rv.w > thr) f.w = 1;
-    *pf = f;
-}
-
-// ---------------------------------------------------------------------------
-// pack / unpack (packing.py:243-278, 369-415) with a precomputed row map
-// ---------------------------------------------------------------------------
-__global__ void k_fill_windows(float2* __restrict__ vis, uint8_t* __restrict__ flags, size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    vis[i] = make_float2(NAN, NAN);
-    flags[i] = 1;
-}
-
-// one thread per (row, chan); loops over corr. grid (ceil(nchan/256), rows)
-__global__ void k_pack(const float2* __restrict__ data, const uint8_t* __restrict__ flag,
-                       const int32_t* __restrict__ row_bl, const int32_t* __restrict__ row_time,
-                       int nchan, int ncorr, int nbl, int ntime, float2* __restrict__ vw,
-                       uint8_t* __restrict__ fw) {
-    int f = blockIdx.x * blockDim.x + threadIdx.x;
-    size_t r = blockIdx.y;
-    if (f >= nchan) return;
-    int bl = row_bl[r], t = row_time[r];
-    if (bl < 0 || bl >= nbl || t < 0 || t >= ntime) return;
-    for (int c = 0; c < ncorr; c++) {
-        size_t i = (r * nchan + f) * (size_t)ncorr + c;
-        size_t o = (((size_t)bl * ncorr + c) * ntime + t) * (size_t)nchan + f;
-        vw[o] = data[i];
-        fw[o] = flag[i];
-    }
-}
-
-__global__ void k_unpack(const uint8_t* __restrict__ fw, const int32_t* __restrict__ row_bl,
-                         const int32_t* __restrict__ row_time, int nchan, int ncorr, int nbl,
-                         int ntime, uint8_t* __restrict__ out) {
-    int f = blockIdx.x * blockDim.x + threadIdx.x;
-    size_t r = blockIdx.y;
-    if (f >= nchan) return;
-    int bl = row_bl[r], t = row_time[r];
-    bool ok = !(bl < 0 || bl >= nbl || t < 0 || t >= ntime);
-    for (int c = 0; c < ncorr; c++) {
-        size_t i = (r * nchan + f) * (size_t)ncorr + c;
-        out[i] = ok ? fw[(((size_t)bl * ncorr + c) * ntime + t) * (size_t)nchan + f] : 0;
-    }
-}
+// tricolour_amd.hip -- host orchestration and C ABI of the MI355X SumThreshold flagger.
+// The kernels live in the headers included below (one translation unit):
+//   tri_common.hpp            overview, error plumbing, device helpers
+//   kernels_elementwise.hpp   K1, K2, K5, K6, K8, pack / unpack, strategy steps
+//   kernels_median.hpp        K3  exact medians
+//   kernels_boxfilter.hpp     K4  box-Gaussian filter (four forms)
+//   kernels_sumthreshold.hpp  K7  fused SumThreshold
+#include "tri_common.hpp"
+#include "kernels_elementwise.hpp"
+#include "kernels_median.hpp"
+#include "kernels_boxfilter.hpp"
+#include "kernels_sumthreshold.hpp"
 
 // ===========================================================================
 // host side
@@ -3046,46 +1179,6 @@ extern "C" int tri_test_median(const float* data, const uint8_t* flags, double* 
     return TRI_OK;
 }
 
-// ===========================================================================
-// "Next" rows: the cheap strategy steps that surround
-// sum_threshold in conf/default.yaml, so a whole strategy chain can stay
-// device-resident.
-// ===========================================================================
-// flag_nans_and_zeros (flagging.py:29-62): out = vis == 0 | isnan(vis) | flags != 0
-template <int VD>
-__global__ void k_flag_nans_zeros(const void* __restrict__ vis, const uint8_t* __restrict__ flags,
-                                  uint8_t* __restrict__ out, size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    bool f;
-    if (VD == TRI_VIS_C64) {
-        float2 z = reinterpret_cast<const float2*>(vis)[i];
-        f = (z.x == 0.0f && z.y == 0.0f) || isnan(z.x) || isnan(z.y);
-    } else {
-        float x = reinterpret_cast<const float*>(vis)[i];
-        f = x == 0.0f || isnan(x);
-    }
-    out[i] = (f || flags[i] != 0) ? 1 : 0;
-}
-
-// out = flags, then for every selected baseline: out |= chan_mask (mode 0) or
-// out = chan_mask (mode 1), broadcast over corr and time.  Serves
-// apply_static_mask (flagging.py:151-172, one call per mask) and flag_autos
-// (flagging.py:90-93: all-ones mask on the auto-correlation baselines).
-// In-place safe (out == flags).  grid (ceil(nchan/256), ncorr*ntime, nbl)
-__global__ void k_apply_bl_chan_mask(const uint8_t* __restrict__ flags, uint8_t* __restrict__ out,
-                                     const uint8_t* __restrict__ bl_sel,
-                                     const uint8_t* __restrict__ chan_mask, int mode, int nchan,
-                                     size_t rows_per_bl) {
-    int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= nchan) return;
-    size_t bl = blockIdx.z;
-    size_t a = (bl * rows_per_bl + blockIdx.y) * (size_t)nchan + f;
-    uint8_t v = flags[a];
-    if (bl_sel[bl]) v = mode == 0 ? (uint8_t)((v | chan_mask[f]) ? 1 : 0) : (uint8_t)(chan_mask[f] ? 1 : 0);
-    out[a] = v;
-}
-
 extern "C" int tri_flag_nans_and_zeros(const void* vis, int vis_dtype, const uint8_t* flags,
                                        uint8_t* out_flags, int64_t n, void* stream) {
     if (!vis || !flags || !out_flags || n < 0) return set_err(TRI_EINVAL, "bad argument");
@@ -3115,3 +1208,4 @@ extern "C" int tri_apply_baseline_channel_mask(const uint8_t* flags, uint8_t* ou
     LAUNCHCHK();
     return TRI_OK;
 }
+
