@@ -475,10 +475,16 @@ k_colfilter_lane4(const float* __restrict__ srcW, const float* __restrict__ srcO
     const int R2 = 2 * r;
     const size_t Cs = (size_t)C;
     const float* src = SRCMODE == 1 ? ((img == 0 ? srcW : srcO) + win * sws_img + cc) : nullptr;
-    const float* sd = SRCMODE != 1 ? srcData + win * sws + cc : nullptr;
+    // SRCMODE 3: input images stored transposed (line c = row c of a [C][ld]
+    // array, ld passed in `sws`); the wave stages 32 positions of its 16 lines
+    // through a small LDS tile (128-byte row segments in, one value per step out)
+    const float* srct = SRCMODE == 3 ? ((img == 0 ? srcW : srcO) + win * sws_img) : nullptr;
+    const int ld = (int)sws;
+    const float* sd = (SRCMODE == 0 || SRCMODE == 2) ? srcData + win * sws + cc : nullptr;
     const unsigned* sf4 = SRCMODE == 2 ? reinterpret_cast<const unsigned*>(srcFlags) + win * (sws / 4) + cc : nullptr;
     float* dst = (img == 0 ? dstW : dstO) + win * dws + cc;
     float* ring = cf_ring + lane;                   // slot k at ring[k * 64]
+    float* tile = cf_ring + (size_t)R2 * 64;        // SRCMODE 3: [32 positions][16 lines + 1]
     for (int k = 0; k < R2; k++) ring[k * 64] = 0.0f;
 
     // per-stage ranges (see K4b): stage p runs for t in [0, tend); its input is
@@ -492,6 +498,15 @@ k_colfilter_lane4(const float* __restrict__ srcW, const float* __restrict__ srcO
     unsigned prew[PF / 4];
     // lane (line, p) loads positions t0 + 4 q + p
     auto issue = [&](int t0) {
+        if (SRCMODE == 3) {
+#pragma unroll
+            for (int q = 0; q < PF / 4; q++) {
+                const int e = q * 64 + lane;        // element of the [16 lines][32 positions] patch
+                const int line = blockIdx.x * 16 + (e >> 5), t = t0 + (e & 31);
+                pre[q] = (line < C && t < n) ? srct[(size_t)line * ld + t] : 0.0f;
+            }
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < PF / 4; q++) {
             int t = t0 + 4 * q + p;
@@ -520,6 +535,16 @@ k_colfilter_lane4(const float* __restrict__ srcW, const float* __restrict__ srcO
                 cur[q] = pre[q];
             }
         }
+        if (SRCMODE == 3) {
+            // registers -> tile (transposed); single-wave workgroup: LDS
+            // operations of one wave execute in order
+#pragma unroll
+            for (int q = 0; q < PF / 4; q++) {
+                const int e = q * 64 + lane;
+                tile[(e & 31) * 17 + (e >> 5)] = cur[q];
+            }
+            __syncthreads();
+        }
         issue(m0 + PF);
 #pragma unroll
         for (int u = 0; u < PF; u++) {
@@ -527,7 +552,8 @@ k_colfilter_lane4(const float* __restrict__ srcW, const float* __restrict__ srcO
             const int t = m - p;                    // this stage's time index
             // sample for stage 0: position m was loaded by lane (u & 3) of the quad
             float xs;
-            if ((u & 3) == 0) xs = dpp_quad<QUAD_PERM(0, 0, 0, 0)>(cur[u >> 2]);
+            if (SRCMODE == 3) xs = tile[u * 17 + (lane >> 2)];
+            else if ((u & 3) == 0) xs = dpp_quad<QUAD_PERM(0, 0, 0, 0)>(cur[u >> 2]);
             else if ((u & 3) == 1) xs = dpp_quad<QUAD_PERM(1, 1, 1, 1)>(cur[u >> 2]);
             else if ((u & 3) == 2) xs = dpp_quad<QUAD_PERM(2, 2, 2, 2)>(cur[u >> 2]);
             else xs = dpp_quad<QUAD_PERM(3, 3, 3, 3)>(cur[u >> 2]);
@@ -551,6 +577,7 @@ k_colfilter_lane4(const float* __restrict__ srcW, const float* __restrict__ srcO
                 }
             }
         }
+        if (SRCMODE == 3) __syncthreads();          // tile fully consumed before it is rewritten
     }
 }
 

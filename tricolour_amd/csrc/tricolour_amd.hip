@@ -616,6 +616,35 @@ int launch_colfilter_t(const Run& r, const float* srcW, const float* srcO, float
     return TRI_OK;
 }
 
+// Lane-per-stage variant of the same (radii 17..80): k_colfilter_lane4<3, *>.
+bool colfilter_t4_usable(int rad) {
+    static const bool off = [] { const char* e = getenv("TRI_FILTER_NO_TIN"); return e && e[0] == '1'; }();
+    return !off && colfilter_use_lane4(rad);
+}
+
+int launch_colfilter_t4(const Run& r, const float* srcW, const float* srcO, float* dstW, float* dstO,
+                        int n, int C, int ld, int rad, size_t sws_img, size_t dws, int64_t W, float* deferred_denom) {
+    float denom = box_denominator(rad);
+    size_t lds = ((size_t)2 * rad * 64 + 32 * 17) * sizeof(float);
+    static const hipError_t attr = [] {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lane4<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lane4<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return e;
+    }();
+    HIPCHK(attr);
+    dim3 grid((unsigned)cdiv(C, 16), (unsigned)W, 2);
+    if (deferred_denom) {
+        *deferred_denom = denom;
+        hipLaunchKernelGGL((k_colfilter_lane4<3, false>), grid, dim3(64), lds, r.st, srcW, srcO, (const float*)nullptr, (const uint8_t*)nullptr,
+                           dstW, dstO, n, C, rad, denom, sws_img, (size_t)ld, dws);
+    } else {
+        hipLaunchKernelGGL((k_colfilter_lane4<3, true>), grid, dim3(64), lds, r.st, srcW, srcO, (const float*)nullptr, (const uint8_t*)nullptr,
+                           dstW, dstO, n, C, rad, denom, sws_img, (size_t)ld, dws);
+    }
+    LAUNCHCHK();
+    return TRI_OK;
+}
+
 // _get_background2d (flagging.py:516-579) for the median spectra of the batch,
 // held in spectrum layout [Fa][Wb] (line axis = channel, column = window).
 // Result: rows [0,Fa) of ws.so hold the background.
@@ -695,7 +724,8 @@ int background2d(const Run& r) {
         float den_t = 0.0f, den_f = 0.0f;   // divisions deferred to the transposes / masked_div
         bool direct_ft = false;
         // frequency stage able to read the time stage's TF images itself (no transposes)
-        const bool tin = colfilter_t_usable(r1);
+        const bool tin4 = !colfilter_t_usable(r1) && colfilter_t4_usable(r1);
+        const bool tin = colfilter_t_usable(r1) || tin4;
         float* den_t_ptr = tin ? nullptr : &den_t;
         // (for the in-place multi-pass kernel, used at large radii, building on
         //  the fly measured faster: 11.4 vs 16.8 ms per call at 128 windows)
@@ -745,7 +775,8 @@ int background2d(const Run& r) {
         //     in-place multi-pass filter, rows [0, Fa) for the single-sweep one ---
         size_t off = colfilter_lds_block(r1, T) > 0 ? 0 : (size_t)4 * r1 * T;
         if (tin && !direct_ft) {
-            rc = launch_colfilter_t(r, ws.Aw, ws.Ao, ws.Bw, ws.Bo, Fa, T, Fa, r1, wsA, wsB, W, &den_f);
+            if (tin4) rc = launch_colfilter_t4(r, ws.Aw, ws.Ao, ws.Bw, ws.Bo, Fa, T, Fa, r1, wsA, wsB, W, &den_f);
+            else rc = launch_colfilter_t(r, ws.Aw, ws.Ao, ws.Bw, ws.Bo, Fa, T, Fa, r1, wsA, wsB, W, &den_f);
             if (rc) return rc;
         } else if (!direct_ft) {
             rc = launch_transpose<float>(r, ws.Aw, ws.Bw + off, T, Fa, wsA, wsB, W, den_t);
