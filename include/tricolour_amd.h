@@ -144,13 +144,16 @@ int tri_fill_windows(void *vis_windows_c64, uint8_t *flag_windows,
 /*
  * Replaces packing._unpack_data / _numpy_unpack_transpose
  * (packing.py:369-415): gather flag windows (bl, corr, time, chan) back to MS
- * row order (row, chan, corr); rows with row_bl < 0 are set to 0.
+ * row order (row, chan, corr); rows with row_bl < 0 are set to 0.  With
+ * any_corr != 0 every correlation of a (row, chan) cell receives the OR over
+ * its correlations -- the equalisation the application applies right after
+ * unpacking (apps/tricolour/app.py:479-480).
  */
 int tri_unpack_data(const uint8_t *flag_windows,
                     const int32_t *row_bl, const int32_t *row_time,
                     int64_t rows, int64_t nchan, int64_t ncorr,
                     int64_t nbl, int64_t ntime,
-                    uint8_t *out_flags, void *stream);
+                    uint8_t *out_flags, int any_corr, void *stream);
 
 /*
  * Replaces tricolour.flagging.flag_nans_and_zeros (flagging.py:29-62):

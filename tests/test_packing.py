@@ -81,6 +81,11 @@ def test_gpu_pack_flag_unpack(gpu, oracle):
             out = torch.from_numpy(d["out_windows"].astype(bool)).cuda()
         up = packing.unpack_data(d["ant1"], d["ant2"], d["time_inv"], d["ubl"], out)
         assert np.array_equal(up.cpu().numpy(), d["unpacked"].astype(bool))
+        # app.py:479-480: flag entire visibility if any correlation is flagged
+        eq = packing.unpack_data(d["ant1"], d["ant2"], d["time_inv"], d["ubl"], out, equalize_corr=True)
+        ref = d["unpacked"].astype(bool)
+        exp_eq = np.broadcast_to(ref.sum(axis=2, keepdims=True) > 0, ref.shape)
+        assert np.array_equal(eq.cpu().numpy(), exp_eq)
         # unpack of a baseline chunk: rows outside stay 0 (packing.py:396-398)
         sub = d["ubl"][2:4].copy()
         up2 = packing.unpack_data(d["ant1"], d["ant2"], d["time_inv"], sub, out[2:4])

@@ -100,7 +100,7 @@ _SIGNATURES = {
     "tri_fill_windows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "tri_unpack_data": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                   C.c_int64, C.c_int64, C.c_int64, C.c_int64,
-                                  C.c_void_p, C.c_void_p]),
+                                  C.c_void_p, C.c_int, C.c_void_p]),
     "tri_flag_nans_and_zeros": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "tri_apply_baseline_channel_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                                   C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),

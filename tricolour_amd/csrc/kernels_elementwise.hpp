@@ -592,17 +592,24 @@ __global__ void k_pack(const float2* __restrict__ data, const uint8_t* __restric
     }
 }
 
+// any_corr: "flag entire visibility if any correlations are flagged"
+// (apps/tricolour/app.py:479-480) fused into the gather
 __global__ void k_unpack(const uint8_t* __restrict__ fw, const int32_t* __restrict__ row_bl,
                          const int32_t* __restrict__ row_time, int nchan, int ncorr, int nbl,
-                         int ntime, uint8_t* __restrict__ out) {
+                         int ntime, uint8_t* __restrict__ out, int any_corr) {
     int f = blockIdx.x * blockDim.x + threadIdx.x;
     size_t r = blockIdx.y;
     if (f >= nchan) return;
     int bl = row_bl[r], t = row_time[r];
     bool ok = !(bl < 0 || bl >= nbl || t < 0 || t >= ntime);
+    uint8_t any = 0;
+    if (any_corr && ok)
+        for (int c = 0; c < ncorr; c++)
+            any |= fw[(((size_t)bl * ncorr + c) * ntime + t) * (size_t)nchan + f] ? 1 : 0;
     for (int c = 0; c < ncorr; c++) {
         size_t i = (r * nchan + f) * (size_t)ncorr + c;
-        out[i] = ok ? fw[(((size_t)bl * ncorr + c) * ntime + t) * (size_t)nchan + f] : 0;
+        uint8_t v = ok ? fw[(((size_t)bl * ncorr + c) * ntime + t) * (size_t)nchan + f] : 0;
+        out[i] = any_corr ? any : v;
     }
 }
 

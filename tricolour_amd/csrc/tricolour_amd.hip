@@ -1081,7 +1081,8 @@ extern "C" int tri_pack_data(const void* data_c64, const uint8_t* flag, const in
 
 extern "C" int tri_unpack_data(const uint8_t* flag_windows, const int32_t* row_bl,
                                const int32_t* row_time, int64_t rows, int64_t nchan, int64_t ncorr,
-                               int64_t nbl, int64_t ntime, uint8_t* out_flags, void* stream) {
+                               int64_t nbl, int64_t ntime, uint8_t* out_flags, int any_corr,
+                               void* stream) {
     if (!flag_windows || !row_bl || !row_time || !out_flags) return set_err(TRI_EINVAL, "NULL pointer argument");
     if (rows < 0 || nchan <= 0 || ncorr <= 0 || nbl < 0 || ntime < 0) return set_err(TRI_EINVAL, "bad shape");
     dim3 grid((unsigned)cdiv(nchan, 256), 1, 1);
@@ -1089,7 +1090,7 @@ extern "C" int tri_unpack_data(const uint8_t* flag_windows, const int32_t* row_b
         int64_t nr = std::min<int64_t>(65535, rows - r0);
         grid.y = (unsigned)nr;
         hipLaunchKernelGGL(k_unpack, grid, dim3(256), 0, (hipStream_t)stream, flag_windows, row_bl + r0, row_time + r0,
-                           (int)nchan, (int)ncorr, (int)nbl, (int)ntime, out_flags + (size_t)r0 * nchan * ncorr);
+                           (int)nchan, (int)ncorr, (int)nbl, (int)ntime, out_flags + (size_t)r0 * nchan * ncorr, any_corr);
         LAUNCHCHK();
     }
     return TRI_OK;

@@ -109,10 +109,12 @@ def pack_data(time_inv, ubl, antenna1, antenna2, data, flags, ntime):
     return vis_w, flag_w.view(torch.bool)
 
 
-def unpack_data(antenna1, antenna2, time_inv, ubl, flag_windows):
+def unpack_data(antenna1, antenna2, time_inv, ubl, flag_windows, equalize_corr=False):
     """Device version of ``packing.unpack_data`` (packing.py:391-425): gathers
     flag windows back to (row, chan, corr); rows whose baseline is not in
-    ``ubl`` stay 0."""
+    ``ubl`` stay 0.  ``equalize_corr=True`` additionally flags every
+    correlation of a visibility if any is flagged (the step the application
+    applies right after unpacking, apps/tricolour/app.py:479-480)."""
     torch = _torch_gpu()
     lib = _lib.lib()
     ubl = np.asarray(ubl)
@@ -128,5 +130,5 @@ def unpack_data(antenna1, antenna2, time_inv, ubl, flag_windows):
     out = torch.empty((rows, nchan, ncorr), dtype=torch.uint8, device=fw.device)
     stream = torch.cuda.current_stream(fw.device).cuda_stream
     _lib.check(lib.tri_unpack_data(fw8.data_ptr(), rb.data_ptr(), rt.data_ptr(), rows, nchan,
-                                   ncorr, nbl, ntime, out.data_ptr(), stream))
+                                   ncorr, nbl, ntime, out.data_ptr(), 1 if equalize_corr else 0, stream))
     return out.view(torch.bool)
