@@ -370,3 +370,38 @@ def test_ska_shaped_window_vs_oracle(gpu, oracle):
     exp = oracle.sum_threshold_flagger(vis.cpu().numpy(), flags.cpu().numpy(), n_threads=2, **kw)
     nbad = int((out != exp).sum())
     assert nbad == 0, "%d of %d flags differ" % (nbad, out.size)
+
+
+def test_flag_dtypes_and_non_contiguous_inputs(gpu, oracle):
+    """flags of any integer type (non-zero = flagged, flagging.py:833-835;
+    cf. the reference's TestAsbool, tests/test_flagging.py:12-34) and
+    non-contiguous views give the same result as contiguous bool input."""
+    import torch
+    rs = np.random.RandomState(8)
+    shape = (2, 2, 32, 64)
+    vis = (rs.standard_normal(shape) + 1j * rs.standard_normal(shape)).astype(np.complex64)
+    vis[..., 9] *= 7
+    flags = rs.uniform(size=shape) < 0.05
+    kw = dict(num_major_iterations=1)
+    exp = oracle.sum_threshold_flagger(vis, flags, **kw)
+    for dt, val in ((np.uint8, 1), (np.int8, -1), (np.uint16, 300), (np.int32, 7), (np.int64, 2**40)):
+        f = (flags.astype(dt) * dt(val))
+        assert np.array_equal(gpu.sum_threshold_flagger(vis, f, **kw), exp), dt
+    # non-contiguous numpy views
+    big_v = np.zeros((2, 2, 32, 128), np.complex64)
+    big_f = np.zeros((2, 2, 32, 128), bool)
+    big_v[..., ::2] = vis
+    big_f[..., ::2] = flags
+    assert np.array_equal(gpu.sum_threshold_flagger(big_v[..., ::2], big_f[..., ::2], **kw), exp)
+    # permuted torch tensors on the device
+    vt = torch.from_numpy(np.ascontiguousarray(vis.transpose(1, 0, 2, 3))).cuda().permute(1, 0, 2, 3)
+    ft = torch.from_numpy(np.ascontiguousarray(flags.transpose(1, 0, 2, 3))).cuda().permute(1, 0, 2, 3)
+    assert not vt.is_contiguous()
+    assert np.array_equal(gpu.sum_threshold_flagger(vt, ft, **kw).cpu().numpy(), exp)
+    # float32 amplitudes and float64 amplitudes
+    amp = np.abs(vis).astype(np.float32)
+    e2 = oracle.sum_threshold_flagger(amp, flags, **kw)
+    assert np.array_equal(gpu.sum_threshold_flagger(amp, flags, **kw), e2)
+    assert np.array_equal(gpu.sum_threshold_flagger(amp.astype(np.float64), flags, **kw), e2)
+    with pytest.raises(TypeError):
+        gpu.sum_threshold_flagger(vis.astype(np.complex128), flags, **kw)
