@@ -176,6 +176,24 @@ int tri_apply_baseline_channel_mask(const uint8_t *flags, uint8_t *out_flags,
                                     int mode, int64_t nbl, int64_t ncorr, int64_t ntime,
                                     int64_t nchan, void *stream);
 
+/*
+ * Replaces tricolour.flagging.uvcontsub_flagger (flagging.py:989-1073): per
+ * correlation product and major cycle, the time-mean spectrum of the unflagged
+ * visibilities is low-passed (first `taylor_degrees` Fourier bins), samples
+ * whose |vis - smooth| exceeds sigma x the MAD-of-MAD of the unflagged
+ * residuals are flagged; cycles below `or_original_from_cycle` REPLACE the
+ * flags, later ones OR them in.  vis complex64 (n_cp, ntime, nchan); out_flags
+ * receives 0/1.  The reference is plain NumPy whose FFT / residual precision
+ * depends on the NumPy version (float32 under NumPy >= 2, followed here), so
+ * parity is by flag-agreement rate, not bit for bit.
+ */
+size_t tri_uvcontsub_workspace_bytes(int64_t batch_windows, int64_t ntime, int64_t nchan);
+int tri_uvcontsub_flagger(const void *vis_c64, const uint8_t *flags, uint8_t *out_flags,
+                          int64_t n_cp, int64_t ntime, int64_t nchan,
+                          int64_t major_cycles, int64_t or_original_from_cycle,
+                          int64_t taylor_degrees, double sigma,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
 /* Thread-local description of the last failure in the calling thread. */
 const char *tri_last_error(void);
 

@@ -389,3 +389,37 @@ def apply_static_mask(flag, ubl, antspos, masks, chan_freqs, chan_widths,
         else:
             raise ValueError("Invalid accumulation_mode")
     return out
+
+
+def uvcontsub_flagger(vis, flags, major_cycles=5, or_original_from_cycle=1,
+                      taylor_degrees=20, sigma=5):
+    """NumPy restatement of flagging.py:989-1073 (the reference routine is
+    itself plain NumPy; results follow the running NumPy's FFT precision)."""
+    import warnings
+    if vis.shape != flags.shape:
+        raise ValueError("vis and flags must have the same shape")
+    nbl, ncorr, ntime, nfreq = vis.shape
+    v = vis.reshape(nbl * ncorr, ntime, nfreq)
+    res = flags.reshape(nbl * ncorr, ntime, nfreq).astype(bool).copy()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for mi in range(major_cycles):
+            start = res.copy()      # every product sees the flags of the cycle start
+            for cp in range(v.shape[0]):
+                if start[cp].all():
+                    continue
+                masked = v[cp].copy()
+                masked[start[cp]] = np.nan
+                avg = np.nanmean(masked, axis=0)
+                avg[np.isnan(avg)] = 0.0
+                spec = np.fft.fft(avg, axis=0)
+                spec[taylor_degrees:] = 0
+                smooth = np.fft.ifft(spec)
+                absres = np.abs(v[cp] - smooth[None, :]).real
+                far = absres.copy()
+                far[start[cp]] = np.nan
+                diff = np.abs(np.abs(far) - np.nanmedian(np.abs(far)))
+                mad = np.nanmedian(np.abs(diff))
+                new = absres > sigma * mad
+                res[cp] = (start[cp] | new) if mi >= or_original_from_cycle else new
+    return res.reshape(nbl, ncorr, ntime, nfreq)

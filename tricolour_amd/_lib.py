@@ -104,6 +104,10 @@ _SIGNATURES = {
     "tri_flag_nans_and_zeros": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "tri_apply_baseline_channel_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                                   C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
+    "tri_uvcontsub_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
+    "tri_uvcontsub_flagger": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                        C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_void_p, C.c_size_t,
+                                        C.c_void_p]),
     "tri_last_error": (C.c_char_p, []),
     "tri_version": (C.c_int, []),
     "tri_bench_sumthreshold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,

@@ -653,3 +653,126 @@ __global__ void k_apply_bl_chan_mask(const uint8_t* __restrict__ flags, uint8_t*
     out[a] = v;
 }
 
+
+// ===========================================================================
+// uvcontsub_flagger (flagging.py:989-1073) -- a pure-NumPy
+// routine in the reference, evaluated here with the float32 semantics of
+// NumPy >= 2 (complex64 FFT, float32 residual).  Tolerance parity only: the
+// reference's FFT rounding cannot be reproduced bit for bit.
+// ===========================================================================
+// flagged-sample count per correlation product (all-flagged products are skipped, :1033-1035)
+// grid (ceil(N/4096), n_cp), block 256
+__global__ void k_uv_count(const uint8_t* __restrict__ rflags, unsigned* __restrict__ cnt, size_t N) {
+    size_t cp = blockIdx.y;
+    size_t i0 = (size_t)blockIdx.x * 4096;
+    unsigned c = 0;
+    for (size_t i = i0 + threadIdx.x; i < min(N, i0 + 4096); i += 256) c += rflags[cp * N + i] ? 1u : 0u;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&cnt[cp], c);
+}
+
+// nanmean over time per channel (:1037-1044): complex64 accumulation in time
+// order, count of samples that are neither flagged nor NaN; none -> 0.
+// grid (ceil(F/256), n_cp)
+__global__ void k_uv_mean(const float2* __restrict__ vis, const uint8_t* __restrict__ rflags,
+                          float2* __restrict__ avg, int T, int F) {
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    size_t cp = blockIdx.y;
+    size_t base = cp * (size_t)T * F + f;
+    float sr = 0.0f, si = 0.0f;
+    long long n = 0;
+    for (int t = 0; t < T; t++) {
+        size_t a = base + (size_t)t * F;
+        float2 z = vis[a];
+        if (!rflags[a] && !isnan(z.x) && !isnan(z.y)) { sr += z.x; si += z.y; n++; }
+    }
+    float2 m = make_float2(0.0f, 0.0f);
+    if (n > 0) m = make_float2((float)((double)sr / (double)n), (float)((double)si / (double)n));
+    avg[cp * (size_t)F + f] = m;
+}
+
+// keep the first K Fourier bins of the mean spectrum (:1046-1055): direct DFT
+// in float64 (K is 20..25), result rounded to complex64.  One workgroup per
+// correlation product.  grid (n_cp), block 256
+__global__ void __launch_bounds__(256)
+k_uv_lowpass(const float2* __restrict__ avg, float2* __restrict__ smooth, int F, int K) {
+    __shared__ double xr[64], xi[64];
+    __shared__ double red[2][4];
+    size_t cp = blockIdx.x;
+    const float2* a = avg + cp * (size_t)F;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int k = 0; k < K; k++) {
+        double pr = 0.0, pi_ = 0.0;
+        for (int f = tid; f < F; f += 256) {
+            double s, c;
+            long long kf = ((long long)k * f) % F;
+            sincospi(2.0 * (double)kf / (double)F, &s, &c);
+            double re = a[f].x, im = a[f].y;
+            // (re + i im) * (c - i s)
+            pr += re * c + im * s;
+            pi_ += im * c - re * s;
+        }
+        for (int o = 32; o > 0; o >>= 1) { pr += __shfl_down(pr, o, 64); pi_ += __shfl_down(pi_, o, 64); }
+        if (lane == 0) { red[0][wave] = pr; red[1][wave] = pi_; }
+        __syncthreads();
+        if (tid == 0) {
+            xr[k] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+            xi[k] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        }
+        __syncthreads();
+    }
+    for (int f = tid; f < F; f += 256) {
+        double sr = 0.0, si = 0.0;
+        for (int k = 0; k < K; k++) {
+            double s, c;
+            long long kf = ((long long)k * f) % F;
+            sincospi(2.0 * (double)kf / (double)F, &s, &c);
+            // X[k] * (c + i s)
+            sr += xr[k] * c - xi[k] * s;
+            si += xr[k] * s + xi[k] * c;
+        }
+        smooth[cp * (size_t)F + f] = make_float2((float)(sr / (double)F), (float)(si / (double)F));
+    }
+}
+
+// absresidual = |vis - smooth| as float32 (:1056) and the mask of samples the
+// MAD ignores: prior flags or NaN residual (:1058-1062).  grid (ceil(N/256), n_cp)
+__global__ void k_uv_resid(const float2* __restrict__ vis, const uint8_t* __restrict__ rflags,
+                           const float2* __restrict__ smooth, float* __restrict__ absres,
+                           uint8_t* __restrict__ mflags, int T, int F) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t N = (size_t)T * F;
+    if (i >= N) return;
+    size_t cp = blockIdx.y;
+    int f = (int)(i % F);
+    float2 z = vis[cp * N + i], s = smooth[cp * (size_t)F + f];
+    float r = tri_hypotf(z.x - s.x, z.y - s.y);
+    absres[cp * N + i] = r;
+    mflags[cp * N + i] = (rflags[cp * N + i] || isnan(r)) ? 1 : 0;
+}
+
+// diff = | |absres| - median | in float32 (:1060)
+__global__ void k_uv_diff(const float* __restrict__ absres, const double* __restrict__ med1,
+                          float* __restrict__ diff, size_t N) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    size_t cp = blockIdx.y;
+    float m = (float)med1[cp];
+    diff[cp * N + i] = fabsf(fabsf(absres[cp * N + i]) - m);
+}
+
+// newflags = absres > sigma * mad (:1065); cycles >= or_from OR with the prior
+// flags, earlier ones replace them (:1067-1071); fully flagged products untouched.
+__global__ void k_uv_apply(const float* __restrict__ absres, const double* __restrict__ mad,
+                           const unsigned* __restrict__ cnt, uint8_t* __restrict__ rflags,
+                           float sigma, int do_or, size_t N) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    size_t cp = blockIdx.y;
+    if (cnt[cp] == (unsigned)N) return;
+    float thr = sigma * (float)mad[cp];
+    bool nf = absres[cp * N + i] > thr;
+    uint8_t old = rflags[cp * N + i];
+    rflags[cp * N + i] = do_or ? (uint8_t)((old || nf) ? 1 : 0) : (uint8_t)(nf ? 1 : 0);
+}

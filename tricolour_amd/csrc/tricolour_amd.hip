@@ -1241,3 +1241,76 @@ extern "C" int tri_apply_baseline_channel_mask(const uint8_t* flags, uint8_t* ou
     return TRI_OK;
 }
 
+
+// ---------------------------------------------------------------------------
+// uvcontsub_flagger (flagging.py:989-1073), SURVEY.md 8f-2
+// ---------------------------------------------------------------------------
+extern "C" size_t tri_uvcontsub_workspace_bytes(int64_t batch, int64_t ntime, int64_t nchan) {
+    if (batch <= 0 || ntime <= 0 || nchan <= 0) return 0;
+    size_t N = (size_t)ntime * nchan, B = (size_t)batch;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    return al(B * N * 4) * 2 + al(B * N) + al(B * nchan * 8) * 2 + al(B * 8) * 2 + al(B * 4) + 4 * 256;
+}
+
+extern "C" int tri_uvcontsub_flagger(const void* vis_c64, const uint8_t* flags, uint8_t* out_flags,
+                                     int64_t n_cp, int64_t ntime, int64_t nchan,
+                                     int64_t major_cycles, int64_t or_original_from_cycle,
+                                     int64_t taylor_degrees, double sigma, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    if (!vis_c64 || !flags || !out_flags) return set_err(TRI_EINVAL, "NULL pointer argument");
+    if (n_cp < 0 || ntime <= 0 || nchan <= 0) return set_err(TRI_EINVAL, "bad shape");
+    if (taylor_degrees < 0 || taylor_degrees > 64) return set_err(TRI_EUNSUPPORTED, "taylor_degrees must be in [0, 64]");
+    if ((int64_t)ntime * nchan >= ((int64_t)1 << 31)) return set_err(TRI_EUNSUPPORTED, "window too large");
+    if (n_cp == 0) return TRI_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int T = (int)ntime, F = (int)nchan;
+    size_t N = (size_t)T * F;
+    size_t one = tri_uvcontsub_workspace_bytes(1, ntime, nchan);
+    if (!workspace || workspace_bytes < one) return set_err(TRI_EWORKSPACE, "workspace of %zu bytes is smaller than the %zu needed for one window", workspace_bytes, one);
+    int64_t Bmax = std::min<int64_t>(n_cp, 16384);
+    while (Bmax > 1 && tri_uvcontsub_workspace_bytes(Bmax, ntime, nchan) > workspace_bytes) Bmax = (Bmax + 1) / 2;
+    while (tri_uvcontsub_workspace_bytes(Bmax, ntime, nchan) > workspace_bytes) Bmax--;
+    Bump b(workspace, workspace_bytes, false);
+    float* absres = b.get<float>((size_t)Bmax * N);
+    float* diff = b.get<float>((size_t)Bmax * N);
+    uint8_t* mflags = b.get<uint8_t>((size_t)Bmax * N);
+    float2* avg = b.get<float2>((size_t)Bmax * F);
+    float2* smooth = b.get<float2>((size_t)Bmax * F);
+    double* med1 = b.get<double>((size_t)Bmax);
+    double* mad = b.get<double>((size_t)Bmax);
+    unsigned* cnt = b.get<unsigned>((size_t)Bmax);
+    int64_t* seg = b.get<int64_t>(2);
+    int64_t hseg[2] = {0, (int64_t)N};
+    HIPCHK(hipMemcpyAsync(seg, hseg, sizeof(hseg), hipMemcpyHostToDevice, st));
+    int K = (int)std::min<int64_t>(taylor_degrees, F);
+    bool vec = N % 4 == 0 && (((uintptr_t)workspace) % 16 == 0);
+    for (int64_t c0 = 0; c0 < n_cp; c0 += Bmax) {
+        int64_t B = std::min(Bmax, n_cp - c0);
+        const float2* v = (const float2*)vis_c64 + (size_t)c0 * N;
+        uint8_t* rf = out_flags + (size_t)c0 * N;
+        // result_flags = flags.copy()  (:1028), normalised to 0/1
+        hipLaunchKernelGGL(k_normalise_flags, dim3((unsigned)cdiv((int64_t)(B * N), 256)), dim3(256), 0, st, flags + (size_t)c0 * N, rf, (size_t)B * N);
+        LAUNCHCHK();
+        for (int64_t mi = 0; mi < major_cycles; mi++) {
+            HIPCHK(hipMemsetAsync(cnt, 0, (size_t)B * sizeof(unsigned), st));
+            hipLaunchKernelGGL(k_uv_count, dim3((unsigned)cdiv((int64_t)N, 4096), (unsigned)B), dim3(256), 0, st, rf, cnt, N);
+            hipLaunchKernelGGL(k_uv_mean, dim3((unsigned)cdiv(F, 256), (unsigned)B), dim3(256), 0, st, v, rf, avg, T, F);
+            hipLaunchKernelGGL(k_uv_lowpass, dim3((unsigned)B), dim3(256), 0, st, avg, smooth, F, K);
+            hipLaunchKernelGGL(k_uv_resid, dim3((unsigned)cdiv((int64_t)N, 256), (unsigned)B), dim3(256), 0, st, v, rf, smooth, absres, mflags, T, F);
+            LAUNCHCHK();
+            // nanmedian over the unflagged, non-NaN residuals of each product (:1061)
+            if (vec)
+                hipLaunchKernelGGL(k_median<true>, dim3(1, (unsigned)B), dim3(256), 0, st, absres, mflags, med1, N, N, (size_t)0, (size_t)1, seg, seg + 1, 1, 1);
+            else
+                hipLaunchKernelGGL(k_median<false>, dim3(1, (unsigned)B), dim3(256), 0, st, absres, mflags, med1, N, N, (size_t)0, (size_t)1, seg, seg + 1, 1, 1);
+            hipLaunchKernelGGL(k_uv_diff, dim3((unsigned)cdiv((int64_t)N, 256), (unsigned)B), dim3(256), 0, st, absres, med1, diff, N);
+            if (vec)
+                hipLaunchKernelGGL(k_median<true>, dim3(1, (unsigned)B), dim3(256), 0, st, diff, mflags, mad, N, N, (size_t)0, (size_t)1, seg, seg + 1, 1, 1);
+            else
+                hipLaunchKernelGGL(k_median<false>, dim3(1, (unsigned)B), dim3(256), 0, st, diff, mflags, mad, N, N, (size_t)0, (size_t)1, seg, seg + 1, 1, 1);
+            hipLaunchKernelGGL(k_uv_apply, dim3((unsigned)cdiv((int64_t)N, 256), (unsigned)B), dim3(256), 0, st, absres, mad, cnt, rf, (float)sigma, mi >= or_original_from_cycle ? 1 : 0, N);
+            LAUNCHCHK();
+        }
+    }
+    return TRI_OK;
+}

@@ -354,3 +354,38 @@ def apply_static_mask(flag, ubl, antspos, masks, chan_freqs, chan_widths,
     bl_sel, chan_masks = static_mask_selection(ubl, antspos, masks, chan_freqs, chan_widths, uvrange)
     torch = _require_gpu()
     return _apply_bl_chan(torch, flag, bl_sel, chan_masks, 0 if accumulation_mode == "or" else 1)
+
+
+def uvcontsub_flagger(vis, flags, major_cycles=5, or_original_from_cycle=1,
+                      taylor_degrees=20, sigma=5):
+    """Iteratively fits a low-order Fourier model to the time-averaged
+    spectrum, subtracts it and clips at ``sigma`` x MAD-of-MAD --
+    ``tricolour.flagging.uvcontsub_flagger`` (flagging.py:989-1073), same
+    arguments.  The reference is plain NumPy (float32 FFT / residuals under
+    NumPy >= 2, float64 before); this follows the float32 semantics, so flags
+    agree with it to within threshold-boundary cases, not bit for bit."""
+    if tuple(vis.shape) != tuple(flags.shape):
+        raise ValueError("vis and flags must have the same shape")       # flagging.py:1018-1019
+    torch = _require_gpu()
+    v, f8, code, from_numpy, device = _as_device_inputs(torch, vis, flags)
+    if code != _lib.TRI_VIS_C64:
+        raise TypeError("tricolour_amd.uvcontsub_flagger: visibilities must be complex64")
+    f8 = _flags_u8(torch, flags, device)
+    nbl, ncorr, ntime, nchan = (int(s) for s in v.shape)
+    lib = _lib.lib()
+    out = torch.empty(f8.shape, dtype=torch.uint8, device=device)
+    n_cp = nbl * ncorr
+    with torch.cuda.device(device):
+        if n_cp > 0 and ntime > 0 and nchan > 0:
+            budget = _workspace_budget(torch, device)
+            batch = max(1, min(n_cp, 4096))
+            while batch > 1 and lib.tri_uvcontsub_workspace_bytes(batch, ntime, nchan) > budget:
+                batch = (batch + 1) // 2
+            nbytes = lib.tri_uvcontsub_workspace_bytes(batch, ntime, nchan)
+            ws = _workspace(torch, device, nbytes)
+            _lib.check(lib.tri_uvcontsub_flagger(
+                v.data_ptr(), f8.data_ptr(), out.data_ptr(), n_cp, ntime, nchan,
+                int(major_cycles), int(or_original_from_cycle), int(taylor_degrees),
+                float(sigma), ws.data_ptr(), ws.numel(),
+                torch.cuda.current_stream(device).cuda_stream))
+    return _like_flags(torch, out, flags, from_numpy)

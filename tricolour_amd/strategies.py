@@ -9,7 +9,7 @@ def apply_strategies(strategies, flag_windows, vis_windows, ubl=None, ant_pos=No
                      chan_freq=None, chan_width=None, masked_channels=None):
     """Runs the ordered ``strategies`` (dicts with ``task`` and ``kwargs``, as
     parsed from the YAML) on (bl, corr, time, chan) tensors and returns the
-    final flags.  ``uvcontsub_flagger`` is not part of this build."""
+    final flags."""
     import torch
     original = flag_windows.clone() if torch.is_tensor(flag_windows) else flag_windows.copy()
     lor = torch.logical_or if torch.is_tensor(flag_windows) else (lambda a, b: a | b)
@@ -23,7 +23,8 @@ def apply_strategies(strategies, flag_windows, vis_windows, ubl=None, ant_pos=No
             new_flags = flagging.sum_threshold_flagger(vis_windows, flag_windows, **kw)
             flag_windows = lor(new_flags, flag_windows)          # strat_executor.py:43
         elif task == "uvcontsub_flagger":
-            raise NotImplementedError("uvcontsub_flagger (SURVEY.md 8f-2) is out of scope of this build")
+            # discards the previous flags by design (strat_executor.py:44-51)
+            flag_windows = flagging.uvcontsub_flagger(vis_windows, flag_windows, **kw)
         elif task == "flag_autos":
             new_flags = flagging.flag_autos(flag_windows, [ubl])
             flag_windows = lor(new_flags, flag_windows)          # :54
