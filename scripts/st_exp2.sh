@@ -1,0 +1,7 @@
+#!/bin/bash
+# experiments on the fused SumThreshold kernel (results are wrong in these builds): stores removed / stage count
+for flags in "-DST_EXP_NOSTORE" "-DST_EXP_NOSTORE -DST_EXP_STAGES=1" "-DST_EXP_STAGES=1" ""; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -shared -std=c++17 -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -mllvm -amdgpu-sched-strategy=max-ilp $flags -o tricolour_amd/libtricolour_amd.so tricolour_amd/csrc/tricolour_amd.hip 2>/dev/null
+  echo -n "[$flags]: "
+  python bench.py --bl 4 --steps 1 --warmup 0 --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['roofline']['achieved'], d['roofline']['ms_per_launch'])"
+done

@@ -21,7 +21,11 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17",
                # IEEE evaluation order: no FMA contraction, no fast-math;
                # correctly rounded float32 division / sqrt
                "-ffp-contract=off", "-fno-fast-math",
-               "-fhip-fp32-correctly-rounded-divide-sqrt"]
+               "-fhip-fp32-correctly-rounded-divide-sqrt",
+               # the kernels are long unrolled blocks of independent dependency
+               # chains: schedule for ILP rather than for occupancy (+6 % on the
+               # fused SumThreshold kernel, neutral elsewhere)
+               "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 
 TRI_OK, TRI_EINVAL, TRI_EUNSUPPORTED, TRI_EWORKSPACE, TRI_EHIP = range(5)
 TRI_VIS_C64, TRI_VIS_F32 = 0, 1

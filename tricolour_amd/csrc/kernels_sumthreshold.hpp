@@ -218,6 +218,7 @@ k_colst_fused(const float* __restrict__ data, const double* __restrict__ med,
 #pragma unroll
     for (int u = 0; u < UN; u++) cur[u] = (u < Lp) ? x[(size_t)u * Cs] : 0.0f;
 
+    unsigned exp_acc = 0;   // ST_EXP_NOSTORE experiment only
     auto block = [&](auto fastc, const int base) {
         constexpr bool fast = decltype(fastc)::value;
 #pragma unroll
@@ -276,7 +277,11 @@ k_colst_fused(const float* __restrict__ data, const double* __restrict__ med,
             }
             const int ef = n - DOUT;
             const int fs = (PH - DOUT) & (UN - 1);
+#ifdef ST_EXP_NOSTORE
+            exp_acc |= accP[fs] | accN[fs];
+#else
             if (fast || (ef >= o0 && ef < o1)) o[(size_t)ef * Cs] = (uint8_t)(accP[fs] | accN[fs]);
+#endif
             accP[fs] = 0;
             accN[fs] = 0;
         }
@@ -287,5 +292,10 @@ k_colst_fused(const float* __restrict__ data, const double* __restrict__ med,
         if (fast) block(std::true_type{}, base);
         else block(std::false_type{}, base);
     }
+#ifdef ST_EXP_NOSTORE
+    o[0] = (uint8_t)exp_acc;
+#else
+    (void)exp_acc;
+#endif
 }
 
