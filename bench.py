@@ -184,6 +184,9 @@ def main():
     args = ap.parse_args()
 
     import torch
+    from tricolour_amd import _lib
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and _lib.needs_build():
+        _lib.build()          # in-tree hipcc build (normally done by __graft_entry__.build())
     import tricolour_amd
     from tricolour_amd import flagging
 
