@@ -253,9 +253,12 @@ def main():
             "dtype": "f32 data / f64 accumulators / u8 flags",
             "data": "synthetic",
             "config": {
-                "workload": "MeerKAT-64 slab: %d of 2016 bl x %d corr x %d time x %d chan per GPU "
-                            "(BASELINE configs[1] processed as HBM-resident baseline slabs), "
-                            "sum_threshold_flagger kwargs=%s" % (args.bl, args.corr, T, F, args.params),
+                "workload": ("MeerKAT-64 slab: %d of 2016 bl x %d corr x %d time x %d chan per GPU "
+                             "(BASELINE configs[1] processed as HBM-resident baseline slabs), "
+                             "sum_threshold_flagger kwargs=%s" % (args.bl, args.corr, T, F, args.params))
+                if (args.corr, T, F) == (4, 1024, 4096) else
+                ("custom window set: %d bl x %d corr x %d time x %d chan per GPU, "
+                 "sum_threshold_flagger kwargs=%s" % (args.bl, args.corr, T, F, args.params)),
                 "baselines_per_gpu": args.bl,
                 "params": args.params,
                 "sharding": "baselines across ranks, no data-path collective",
