@@ -139,9 +139,12 @@ __global__ void k_masked_div(const float* __restrict__ w, float* __restrict__ o,
     float bg = (wv == 0.0f) ? NAN : ov / wv;
     // remember which lines (columns) hold a NaN: only those need the
     // sequential interpolation pass
-    if (MODE == 0 && nanflag && isnan(bg)) nanflag[win * (size_t)C + (i % C)] = 1;
+    if (MODE != 1 && nanflag && isnan(bg)) nanflag[win * (size_t)C + (i % C)] = 1;
     if (MODE == 1) bg = fabsf(data[win * ws_data + i] - bg);
     o[win * ws_wo + i] = bg;
+    // MODE 2: additionally the signed residual data - bg (flagging.py:962), written over
+    // the weight image, which is dead from here on
+    if (MODE == 2) const_cast<float*>(w)[win * ws_wo + i] = data[win * ws_data + i] - bg;
 }
 
 // flags |= resid > median * (MAD_NORMAL * reject)   (flagging.py:567-574);
@@ -169,7 +172,8 @@ __global__ void k_reject(const float* __restrict__ resid, uint8_t* __restrict__ 
 // grid (ceil(C/256), W)
 // ---------------------------------------------------------------------------
 __global__ void k_colinterp(float* __restrict__ a, int L, int C, size_t ws,
-                            const uint8_t* __restrict__ nanflag) {
+                            const uint8_t* __restrict__ nanflag, const float* __restrict__ data,
+                            size_t ws_data, float* __restrict__ resid) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     if (nanflag && !nanflag[(size_t)blockIdx.y * C + c]) return;   // no NaN in this line
@@ -198,6 +202,12 @@ __global__ void k_colinterp(float* __restrict__ a, int L, int C, size_t ws,
     if (run < L) {
         float fill = last < 0 ? 0.0f : lastv;  // all NaN -> zeros; else extrapolate forwards
         for (int j = run; j < L; j++) x[(size_t)j * Cs] = fill;
+    }
+    // the residual of a repaired line was formed from the NaN background: redo it
+    if (resid) {
+        const float* d = data + (size_t)blockIdx.y * ws_data + c;
+        float* rr = resid + (size_t)blockIdx.y * ws + c;
+        for (int j = 0; j < L; j++) rr[(size_t)j * Cs] = d[(size_t)j * Cs] - x[(size_t)j * Cs];
     }
 }
 
@@ -521,7 +531,7 @@ __global__ void k_masked_div4(const float* __restrict__ w, float* __restrict__ o
     }
     float bg[4] = {(wv.x == 0.0f) ? NAN : ov.x / wv.x, (wv.y == 0.0f) ? NAN : ov.y / wv.y,
                    (wv.z == 0.0f) ? NAN : ov.z / wv.z, (wv.w == 0.0f) ? NAN : ov.w / wv.w};
-    if (MODE == 0 && nanflag) {
+    if (MODE != 1 && nanflag) {
         int cb = (int)((i * 4) % C);   // C % 4 == 0: the four samples are columns cb .. cb + 3
 #pragma unroll
         for (int k = 0; k < 4; k++)
@@ -533,6 +543,11 @@ __global__ void k_masked_div4(const float* __restrict__ w, float* __restrict__ o
         bg[2] = fabsf(dv.z - bg[2]); bg[3] = fabsf(dv.w - bg[3]);
     }
     *po = make_float4(bg[0], bg[1], bg[2], bg[3]);
+    if (MODE == 2) {   // signed residual over the (dead) weight image
+        float4 dv = reinterpret_cast<const float4*>(data + win * ws_data)[i];
+        reinterpret_cast<float4*>(const_cast<float*>(w) + win * ws_wo)[i] =
+            make_float4(dv.x - bg[0], dv.y - bg[1], dv.z - bg[2], dv.w - bg[3]);
+    }
 }
 
 __global__ void k_sub4(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,

@@ -679,14 +679,15 @@ int spectrum_background(const Run& r) {
             LAUNCHCHK();
         }
     }
-    hipLaunchKernelGGL(k_colinterp, dim3((unsigned)cdiv(Wn, 256), 1), dim3(256), 0, r.st, ws.so, Fa, Wn, (size_t)0, (const uint8_t*)nullptr);
+    hipLaunchKernelGGL(k_colinterp, dim3((unsigned)cdiv(Wn, 256), 1), dim3(256), 0, r.st, ws.so, Fa, Wn, (size_t)0, (const uint8_t*)nullptr, (const float*)nullptr, (size_t)0, (float*)nullptr);
     LAUNCHCHK();
     return TRI_OK;
 }
 
 // _get_background2d (flagging.py:516-579) for every window of the batch.
 // In: dataTF / dataFT, flagsTF (spectral flags already OR-ed in).  Out: the
-// background in FT layout in rows [0,Fa) of ws.Bo (window stride PF*T).
+// background in FT layout in rows [0,Fa) of ws.Bo and the residual
+// data - background in rows [0,Fa) of ws.Bw (window stride PF*T).
 int background2d(const Run& r) {
     const Plan& pl = r.pl;
     const Ws& ws = r.ws;
@@ -793,7 +794,7 @@ int background2d(const Run& r) {
             // ws.rowcnt (W * T ints, idle until the end of the iteration) doubles as the
             // per-line "background holds a NaN" marker
             HIPCHK(hipMemsetAsync(ws.rowcnt, 0, (size_t)W * T, r.st));
-            rc = launch_masked_div<0>(r, ws.Bw, ws.Bo, ws.dataFT, N, wsB, N, W, den_f, reinterpret_cast<uint8_t*>(ws.rowcnt), T);
+            rc = launch_masked_div<2>(r, ws.Bw, ws.Bo, ws.dataFT, N, wsB, N, W, den_f, reinterpret_cast<uint8_t*>(ws.rowcnt), T);
             if (rc) return rc;
         } else {
             rc = launch_masked_div<1>(r, ws.Bw, ws.Bo, ws.dataFT, N, wsB, N, W, den_f);
@@ -814,7 +815,7 @@ int background2d(const Run& r) {
             if (rc) return rc;
         }
     }
-    hipLaunchKernelGGL(k_colinterp, dim3((unsigned)cdiv(T, 256), (unsigned)W), dim3(256), 0, r.st, ws.Bo, Fa, T, wsB, reinterpret_cast<const uint8_t*>(ws.rowcnt));
+    hipLaunchKernelGGL(k_colinterp, dim3((unsigned)cdiv(T, 256), (unsigned)W), dim3(256), 0, r.st, ws.Bo, Fa, T, wsB, reinterpret_cast<const uint8_t*>(ws.rowcnt), (const float*)ws.dataFT, N, ws.Bw);
     LAUNCHCHK();
     return TRI_OK;
 }
@@ -875,9 +876,9 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
     if (tap && r.dbg) {
         HIPCHK(hipMemcpyAsync(r.dbg->f32 + Fa, ws.Bo, N * sizeof(float), hipMemcpyDeviceToDevice, r.st));
     }
-    rc = launch_sub(r, ws.dataFT, ws.Bo, ws.Bo, N, N, wsB, wsB, W);
-    if (rc) return rc;
-    float* residFT = ws.Bo;   // window stride wsB
+    // the residual data - background was written by the final masked division
+    // (and redone by the interpolation pass on repaired lines) into ws.Bw
+    float* residFT = ws.Bw;   // window stride wsB
     float* residTF = ws.Aw;   // window stride N (the time-axis scratch is free again)
     rc = launch_transpose<float>(r, residFT, residTF, Fa, T, wsB, N, W);
     if (rc) return rc;
