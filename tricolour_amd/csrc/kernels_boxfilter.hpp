@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(256)
 k_colfilter_lds(const float* __restrict__ srcW, const float* __restrict__ srcO,
                 const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags,
                 float* __restrict__ dstW, float* __restrict__ dstO,
-                int n, int C, int r, float denom, size_t sws_img, size_t sws, size_t dws) {
+                int n, int C, int r, float denom, size_t sws_img, size_t sws, size_t dws, int intw) {
     extern __shared__ float cf_ring[];
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
@@ -176,8 +176,17 @@ k_colfilter_lds(const float* __restrict__ srcW, const float* __restrict__ srcO,
         return src[(size_t)t * Cs];
     };
 
-    double s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0;
-    float o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;       // stage outputs of the previous step
+    // The cascade, generic in its arithmetic: float32 values with float64
+    // accumulators (the reference's types), or -- for the WEIGHT image of the
+    // time-axis stage, whose values are small integers throughout (0/1 in,
+    // pass sums <= (2r+1)^4 <= 2^24, all exactly representable in float32 and
+    // float64) -- plain int32, which yields bit-identical outputs at a
+    // fraction of the FP64 issue cost.
+    auto cascade = [&](auto intw_tag) {
+    using V = typename std::conditional<decltype(intw_tag)::value, int, float>::type;
+    using A = typename std::conditional<decltype(intw_tag)::value, int, double>::type;
+    A s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+    V o1 = 0, o2 = 0, o3 = 0;                    // stage outputs of the previous step
     int slot1 = 0, slot2 = 0, slot3 = 0, slot4 = 0;
     const int total = n + 4 * r + 3;
     // Deep prefetch: with the LDS rings capping occupancy at 2 waves / SIMD,
@@ -218,11 +227,11 @@ k_colfilter_lds(const float* __restrict__ srcW, const float* __restrict__ srcO,
     // Ring reads are issued one step ahead (R2 >= 2, so the slot read for step
     // m + 1 differs from the slot written at step m): their LDS latency hides
     // behind the arithmetic of the current step instead of stalling each stage.
-    float* rp1 = ring;
-    float* rp2 = ring + (size_t)(1 * R2) * BT;
-    float* rp3 = ring + (size_t)(2 * R2) * BT;
-    float* rp4 = ring + (size_t)(3 * R2) * BT;
-    float old1 = 0.0f, old2 = 0.0f, old3 = 0.0f, old4 = 0.0f;   // rings start zeroed
+    V* rp1 = reinterpret_cast<V*>(ring);
+    V* rp2 = reinterpret_cast<V*>(ring) + (size_t)(1 * R2) * BT;
+    V* rp3 = reinterpret_cast<V*>(ring) + (size_t)(2 * R2) * BT;
+    V* rp4 = reinterpret_cast<V*>(ring) + (size_t)(3 * R2) * BT;
+    V old1 = 0, old2 = 0, old3 = 0, old4 = 0;   // rings start zeroed (all-zero bits in either type)
     auto nextslot = [&](int sl) { return (sl + 1 == R2) ? 0 : sl + 1; };
 
     auto step = [&](auto fastc, const int m, const float xin) {
@@ -234,16 +243,16 @@ k_colfilter_lds(const float* __restrict__ srcW, const float* __restrict__ srcO,
         const int ns1 = a1 ? nextslot(slot1) : slot1, ns2 = a2 ? nextslot(slot2) : slot2;
         const int ns3 = a3 ? nextslot(slot3) : slot3, ns4 = a4 ? nextslot(slot4) : slot4;
         // prefetch next step's trailing samples
-        const float nold1 = rp1[(size_t)ns1 * BT], nold2 = rp2[(size_t)ns2 * BT];
-        const float nold3 = rp3[(size_t)ns3 * BT], nold4 = rp4[(size_t)ns4 * BT];
+        const V nold1 = rp1[(size_t)ns1 * BT], nold2 = rp2[(size_t)ns2 * BT];
+        const V nold3 = rp3[(size_t)ns3 * BT], nold4 = rp4[(size_t)ns4 * BT];
         // stage 4 (time t4 = m - 3): input out_3[t4], present for 2r <= t4 < n + 4r
         if (a4) {
             const int t = m - 3;
-            float in = (FAST || t >= R2) ? o3 : 0.0f;
+            V in = (FAST || t >= R2) ? o3 : (V)0;
             rp4[(size_t)slot4 * BT] = in;
-            s4 += (double)in;
+            s4 += (A)in;
             float out = (float)s4;
-            s4 -= (double)old4;
+            s4 -= (A)old4;
             int i = t - 4 * r;
             if (FAST || i >= 0) {
                 float y = DIV ? out / denom : out;
@@ -260,27 +269,27 @@ k_colfilter_lds(const float* __restrict__ srcW, const float* __restrict__ srcO,
         }
         // stage 3 (t3 = m - 2): input out_2[t3], t3 in [0, n + 4r)
         if (a3) {
-            float in = o2;
+            V in = o2;
             rp3[(size_t)slot3 * BT] = in;
-            s3 += (double)in;
-            o3 = (float)s3;
-            s3 -= (double)old3;
+            s3 += (A)in;
+            o3 = (V)s3;
+            s3 -= (A)old3;
         }
         // stage 2 (t2 = m - 1): input out_1[t2] for t2 < n + 2r, then drains to n + 4r
         if (a2) {
-            float in = (FAST || m - 1 < n + R2) ? o1 : 0.0f;
+            V in = (FAST || m - 1 < n + R2) ? o1 : (V)0;
             rp2[(size_t)slot2 * BT] = in;
-            s2 += (double)in;
-            o2 = (float)s2;
-            s2 -= (double)old2;
+            s2 += (A)in;
+            o2 = (V)s2;
+            s2 -= (A)old2;
         }
         // stage 1 (t1 = m): input data[t1] for t1 < n, drains to n + 2r
         if (a1) {
-            float in = (FAST || m < n) ? xin : 0.0f;
+            V in = (FAST || m < n) ? (V)xin : (V)0;
             rp1[(size_t)slot1 * BT] = in;
-            s1 += (double)in;
-            o1 = (float)s1;
-            s1 -= (double)old1;
+            s1 += (A)in;
+            o1 = (V)s1;
+            s1 -= (A)old1;
         }
         // a stage that did not run keeps its pending trailing sample
         if (a1) { old1 = nold1; slot1 = ns1; }
@@ -309,6 +318,9 @@ k_colfilter_lds(const float* __restrict__ srcW, const float* __restrict__ srcO,
             for (int u = 0; u < PF; u++) step(std::false_type{}, m0 + u, cur[u]);
         }
     }
+    };
+    if (intw && img == 0) cascade(std::true_type{});
+    else cascade(std::false_type{});
 }
 
 // ---------------------------------------------------------------------------

@@ -413,8 +413,10 @@ inline bool colfilter_use_lane4(int rad) {
 int launch_colfilter(const Run& r, int srcmode, float* bufW, float* bufO, const float* srcData,
                      const uint8_t* srcFlags, float* dstW, float* dstO, int n, int C, int rad,
                      size_t bws, size_t sws, size_t dws, int64_t W, float* deferred_denom = nullptr,
-                     bool transposed_out = false) {
+                     bool transposed_out = false, bool weights_are_01 = false) {
     float denom = box_denominator(rad);
+    // integer arithmetic for the weight image is exact while (2r+1)^4 <= 2^24
+    const int intw = (weights_are_01 && rad <= 31) ? 1 : 0;
     int bt = colfilter_lds_block(rad, C);
     if (deferred_denom) *deferred_denom = 0.0f;
     if (bt > 0 && colfilter_use_lane4(rad) && !transposed_out) {
@@ -479,27 +481,27 @@ int launch_colfilter(const Run& r, int srcmode, float* bufW, float* bufO, const 
             if (deferred_denom) {
                 *deferred_denom = denom;
                 hipLaunchKernelGGL((k_colfilter_lds<2, false, false>), grid, dim3(bt), lds, r.st, (const float*)nullptr, (const float*)nullptr,
-                                   srcData, srcFlags, dstW, dstO, n, C, rad, denom, (size_t)0, sws, dws);
+                                   srcData, srcFlags, dstW, dstO, n, C, rad, denom, (size_t)0, sws, dws, intw);
             } else {
                 hipLaunchKernelGGL((k_colfilter_lds<2, true, false>), grid, dim3(bt), lds, r.st, (const float*)nullptr, (const float*)nullptr,
-                                   srcData, srcFlags, dstW, dstO, n, C, rad, denom, (size_t)0, sws, dws);
+                                   srcData, srcFlags, dstW, dstO, n, C, rad, denom, (size_t)0, sws, dws, intw);
             }
             LAUNCHCHK();
             return TRI_OK;
         }
         if (transposed_out)
             hipLaunchKernelGGL((k_colfilter_lds<1, true, true>), grid, dim3(bt), lds, r.st, (const float*)bufW, (const float*)bufO,
-                               srcData, srcFlags, dstW, dstO, n, C, rad, denom, bws, sws, dws);
+                               srcData, srcFlags, dstW, dstO, n, C, rad, denom, bws, sws, dws, intw);
         else if (srcmode == 0)
             hipLaunchKernelGGL((k_colfilter_lds<0, true, false>), grid, dim3(bt), lds, r.st, (const float*)nullptr, (const float*)nullptr,
-                               srcData, srcFlags, dstW, dstO, n, C, rad, denom, (size_t)0, sws, dws);
+                               srcData, srcFlags, dstW, dstO, n, C, rad, denom, (size_t)0, sws, dws, intw);
         else if (deferred_denom) {
             *deferred_denom = denom;
             hipLaunchKernelGGL((k_colfilter_lds<1, false, false>), grid, dim3(bt), lds, r.st, (const float*)bufW, (const float*)bufO,
-                               srcData, srcFlags, dstW, dstO, n, C, rad, denom, bws, sws, dws);
+                               srcData, srcFlags, dstW, dstO, n, C, rad, denom, bws, sws, dws, intw);
         } else
             hipLaunchKernelGGL((k_colfilter_lds<1, true, false>), grid, dim3(bt), lds, r.st, (const float*)bufW, (const float*)bufO,
-                               srcData, srcFlags, dstW, dstO, n, C, rad, denom, bws, sws, dws);
+                               srcData, srcFlags, dstW, dstO, n, C, rad, denom, bws, sws, dws, intw);
         LAUNCHCHK();
         return TRI_OK;
     }
@@ -661,7 +663,7 @@ int spectrum_background(const Run& r) {
         double sigma = (double)(final_pass ? 1 : ext) * r.p->spike_width_freq;  // flagging.py:554, 576
         int rad = (int)box_radius(sigma);
         if (rad > 0) {
-            int rc = launch_colfilter(r, 0, ws.sw, ws.so, ws.sdata, ws.sbgf, ws.sw, ws.so, Fa, Wn, rad, 0, 0, 0, 1);
+            int rc = launch_colfilter(r, 0, ws.sw, ws.so, ws.sdata, ws.sbgf, ws.sw, ws.so, Fa, Wn, rad, 0, 0, 0, 1, nullptr, false, true);
             if (rc) return rc;
         } else {
             hipLaunchKernelGGL(k_build_wo, grid1(nS, 1), dim3(256), 0, r.st, ws.sdata, ws.sbgf, ws.sw, ws.so, nS, (size_t)0, (size_t)0);
@@ -732,7 +734,7 @@ int background2d(const Run& r) {
         //  the fly measured faster: 11.4 vs 16.8 ms per call at 128 windows)
         if (r0 > 0 && packed && colfilter_lds_block(r0, Fa) > 0) {
             // single sweep straight from (data, packed flags): no image build
-            rc = launch_colfilter(r, 2, ws.Aw, ws.Ao, ws.dataTF, ws.bgfTF, ws.Aw, ws.Ao, T, Fa, r0, wsA, N, wsA, W, den_t_ptr);
+            rc = launch_colfilter(r, 2, ws.Aw, ws.Ao, ws.dataTF, ws.bgfTF, ws.Aw, ws.Ao, T, Fa, r0, wsA, N, wsA, W, den_t_ptr, false, true);
             if (rc) return rc;
         } else if (r0 > 0 && !packed && prebuild && colfilter_lds_block(r0, Fa) > 0) {
             const bool lds_path = true;
@@ -750,7 +752,7 @@ int background2d(const Run& r) {
                 size_t off2 = colfilter_lds_block(r1, T) > 0 ? 0 : (size_t)4 * r1 * T;
                 rc = launch_colfilter(r, 1, ws.Aw, ws.Ao, nullptr, nullptr, ws.Bw + off2, ws.Bo + off2, T, Fa, r0, wsA, 0, wsB, W, nullptr, true);
             } else {
-                rc = launch_colfilter(r, 1, ws.Aw, ws.Ao, nullptr, nullptr, ws.Aw, ws.Ao, T, Fa, r0, wsA, 0, wsA, W, den_t_ptr);
+                rc = launch_colfilter(r, 1, ws.Aw, ws.Ao, nullptr, nullptr, ws.Aw, ws.Ao, T, Fa, r0, wsA, 0, wsA, W, den_t_ptr, false, true);
             }
             if (rc) return rc;
         } else if (r0 > 0) {
