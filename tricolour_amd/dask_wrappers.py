@@ -1,62 +1,52 @@
-"""Graph-level drop-in for ``tricolour.dask_wrappers.sum_threshold_flagger``
-(reference ``tricolour/dask_wrappers.py:23-46``): same signature, same
-``blockwise`` layer over the window schema, same return value; the per-block
-callable is :func:`tricolour_amd.flagging.sum_threshold_flagger` (numpy block
-in -> H2D -> HIP kernels -> D2H -> numpy block out), so it slots into the
-existing graph over Measurement Sets unchanged.
+"""Graph-level drop-ins for ``tricolour.dask_wrappers.sum_threshold_flagger``
+and ``uvcontsub_flagger`` (reference ``tricolour/dask_wrappers.py:23-66``).
 
-dask is imported lazily: it is needed only when the graph is built.
+Same call signatures and the same result as the reference wrappers: a dask
+array with the chunking of ``vis`` and the dtype of ``flag`` whose graph holds
+one task per baseline chunk.  Each task hands its numpy window block to the
+HIP path (:mod:`tricolour_amd.flagging`: H2D, kernels, D2H), so the wrappers
+slot into the existing graph over Measurement Sets unchanged.
+
+dask is imported lazily: it is only needed when a graph is built.
 """
 from tricolour_amd.flagging import sum_threshold_flagger as amd_sum_threshold_flagger
 from tricolour_amd.flagging import uvcontsub_flagger as amd_uvcontsub_flagger
 from tricolour_amd.packing import _WINDOW_SCHEMA
 
 
-def sum_threshold_flagger(vis, flag, **kwargs):
-    """
-    Dask wrapper for :func:`tricolour_amd.flagging.sum_threshold_flagger`
-    """
+def _window_blockwise(per_block, layer_name, vis, flag, kwargs):
+    """One blockwise layer over the (bl, corr, time, chan) window schema.
+
+    The low-level ``dask.blockwise.blockwise`` is used (as the reference does)
+    because window blocks are chunked along ``bl`` only and differ in size, so
+    the block counts have to be given explicitly."""
     import dask.array as da
-    import dask.blockwise as db
+    from dask.blockwise import blockwise
     from dask.highlevelgraph import HighLevelGraph
 
-    # dask.blockwise.blockwise rather than dask.array.blockwise, as in the
-    # reference: blocks are chunked along "bl" only and differ in size
+    block_counts = {vis.name: vis.numblocks, flag.name: flag.numblocks}
+    layer = blockwise(per_block, layer_name, _WINDOW_SCHEMA,
+                      vis.name, _WINDOW_SCHEMA, flag.name, _WINDOW_SCHEMA,
+                      numblocks=block_counts, **kwargs)
+    graph = HighLevelGraph.from_collections(layer_name, layer, dependencies=(vis, flag))
+    return da.Array(graph, layer_name, chunks=vis.chunks, dtype=flag.dtype)
+
+
+def sum_threshold_flagger(vis, flag, **kwargs):
+    """Dask wrapper for :func:`tricolour_amd.flagging.sum_threshold_flagger`;
+    the layer is named ``sum-threshold-flagger-<tokenize(vis, flag, kwargs)>``
+    exactly as in the reference."""
+    import dask.array as da
     token = da.core.tokenize(vis, flag, kwargs)
-    name = 'sum-threshold-flagger-' + token
-
-    layers = db.blockwise(amd_sum_threshold_flagger, name, _WINDOW_SCHEMA,
-                          vis.name, _WINDOW_SCHEMA,
-                          flag.name, _WINDOW_SCHEMA,
-                          numblocks={
-                              vis.name: vis.numblocks,
-                              flag.name: flag.numblocks,
-                          },
-                          **kwargs)
-
-    graph = HighLevelGraph.from_collections(name, layers, (vis, flag))
-    return da.Array(graph, name, vis.chunks, dtype=flag.dtype)
+    return _window_blockwise(amd_sum_threshold_flagger, 'sum-threshold-flagger-' + token,
+                             vis, flag, kwargs)
 
 
 def uvcontsub_flagger(vis, flag, **kwargs):
-    """
-    Dask wrapper for :func:`tricolour_amd.flagging.uvcontsub_flagger`
-    (reference ``tricolour/dask_wrappers.py:49-66``)
-    """
+    """Dask wrapper for :func:`tricolour_amd.flagging.uvcontsub_flagger`; the
+    layer is named ``uvcontsub-flagger-<tokenize(vis, flag, **kwargs)>`` (the
+    reference passes the keyword arguments to ``tokenize`` unpacked here)."""
     import dask.array as da
-    import dask.blockwise as db
-    from dask.highlevelgraph import HighLevelGraph
-
-    name = 'uvcontsub-flagger-' + da.core.tokenize(vis, flag, **kwargs)
-
-    layers = db.blockwise(amd_uvcontsub_flagger, name, _WINDOW_SCHEMA,
-                          vis.name, _WINDOW_SCHEMA,
-                          flag.name, _WINDOW_SCHEMA,
-                          numblocks={
-                              vis.name: vis.numblocks,
-                              flag.name: flag.numblocks,
-                          },
-                          **kwargs)
-
-    graph = HighLevelGraph.from_collections(name, layers, (vis, flag))
-    return da.Array(graph, name, vis.chunks, dtype=flag.dtype)
+    token = da.core.tokenize(vis, flag, **kwargs)
+    return _window_blockwise(amd_uvcontsub_flagger, 'uvcontsub-flagger-' + token,
+                             vis, flag, kwargs)
