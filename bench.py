@@ -140,7 +140,8 @@ def roofline_sumthreshold(torch, device, T, F, kw):
         _lib.check(lib.tri_bench_sumthreshold(data.data_ptr(), mad.data_ptr(), out.data_ptr(),
                                               nwin, T, F, warr, len(wins),
                                               float(kw.get("outlier_nsigma", 4.5)),
-                                              float(kw.get("rho", 1.3)), 0, reps,
+                                              float(kw.get("rho", 1.3)),
+                                              int(os.environ.get("TRI_BENCH_ST_VARIANT", "0")), reps,
                                               C.byref(ms), stream))
     samples = nwin * T * F
     achieved = samples * ST_BYTES_PER_SAMPLE / (ms.value * 1e-3) / 1e9

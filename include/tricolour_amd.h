@@ -214,7 +214,9 @@ int tri_version(void);
  *   mad  (n_win, n_col) float64 medians of |data| (NaN = nothing unflagged)
  *   out  (n_win, n_line, n_col) uint8
  * `variant`: 0 = best available for these windows, 1 = generic (dynamic
- * windows, global rings), 2 = register cascade (windows 1,2,4,8 only).
+ * windows, global rings), 2 = register cascade (windows 1,2,4,8 only),
+ * 3 = lane-mask cascade (windows 1,2,4,8, window below 2^32 bytes; what 0
+ * selects for those).
  */
 int tri_bench_sumthreshold(const float *data, const double *mad, uint8_t *out,
                            int64_t n_win, int64_t n_line, int64_t n_col,

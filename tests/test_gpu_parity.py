@@ -154,6 +154,34 @@ def test_fused_sumthreshold_kernel_vs_generic_and_oracle(gpu, oracle, shape):
     if windows == [1, 2, 4, 8]:
         fused = _run_st_kernel(data, mad, windows, 4.5, 1.3, 2)
         assert np.array_equal(fused, gen)
+        mask = _run_st_kernel(data, mad, windows, 4.5, 1.3, 3)
+        assert np.array_equal(mask, gen), "lane-mask cascade"
+
+
+@pytest.mark.parametrize("n_line", [16, 40, 100])
+def test_sumthreshold_hit_only_in_last_window_position(gpu, oracle, n_line):
+    """A sample that only the widest window STARTING at it can flag (seven
+    strong outliers follow it): the dilation of the last stage has to reach back
+    w-1 positions before that position's flag is written out."""
+    n_col = 64
+    rs = np.random.RandomState(11)
+    data = (rs.standard_normal((1, n_line, n_col)) * 0.3).astype(np.float32)
+    for c in range(n_col):
+        p = 1 + (c * 5) % (n_line - 9)
+        sign = -1.0 if c % 2 else 1.0
+        data[0, p, c] = sign * np.float32(0.92)
+        data[0, p + 1:p + 8, c] = sign * (5.2 + 0.01 * np.arange(7, dtype=np.float32))
+    flags = np.zeros(data.shape, bool)
+    mad = np.full((1, n_col), 0.2714695930480957, np.float64)
+    windows = [1, 2, 4, 8]
+    gen = _run_st_kernel(data, mad, windows, 4.5, 1.3, 1)
+    assert gen.any() and not gen.all()
+    for variant in (2, 3):
+        assert np.array_equal(_run_st_kernel(data, mad, windows, 4.5, 1.3, variant), gen), "variant %d" % variant
+    # the pattern does what it is meant to: position p is flagged, p - 1 is not
+    for c in range(n_col):
+        p = 1 + (c * 5) % (n_line - 9)
+        assert gen[0, p, c] and not gen[0, p - 1, c], "column %d" % c
 
 
 def _np_median_abs(vals):

@@ -10,7 +10,9 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtricolour_amd.so")
+# TRICOLOUR_AMD_LIB: developer override, loads another build of the same sources
+# (kernel A/B experiments, scripts/build_variants.sh)
+LIB_PATH = os.environ.get("TRICOLOUR_AMD_LIB") or os.path.join(_HERE, "libtricolour_amd.so")
 SOURCES = [os.path.join(_HERE, "csrc", "tricolour_amd.hip")]   # one translation unit
 DEPENDS = [os.path.join(_HERE, "csrc", f) for f in (
     "tri_common.hpp", "kernels_elementwise.hpp", "kernels_median.hpp", "kernels_boxfilter.hpp",

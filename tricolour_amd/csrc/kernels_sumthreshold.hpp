@@ -299,3 +299,209 @@ k_colst_fused(const float* __restrict__ data, const double* __restrict__ med,
 #endif
 }
 
+
+// ---------------------------------------------------------------------------
+// K7c  Lane-mask SumThreshold cascade for windows {1,2,4,8}: the arithmetic of
+// K7b (same float64 operations, same order), but every per-sample flag lives
+// as a 64-bit wave lane mask in scalar registers instead of a 0/1 value per
+// lane:
+//   * fP[q], fN[q]: positive / negative flags of line position q (mod 16) for
+//     the 64 lines of the wave.  A hit of stage j at ingest position i is
+//     OR-ed straight into its w positions i-w+1..i (s_or_b64), so the
+//     dilation needs no hit history and no vector instruction;
+//   * the clamp of stage j >= 1 is  m = (fP & (x > thr)) | (fN & (x < -thr)),
+//     cl = m ? copysign(thr, x) : x  -- two compares, one bit-field insert and
+//     two selects;
+//   * the last stage does not need the sign of its hits: it tests |S| > T
+//     and ORs into a single ring fA = fP | fN, merged when a position reaches
+//     the last stage (positive / negative flags only matter to later clamps);
+//   * samples are converted to float64 once and kept in an 8-deep ring.
+// The vector ALU is left with the float64 adds / compares and the selects
+// (about 35 instructions per sample instead of 58 in K7b); the
+// mask algebra (about 33 instructions) runs on the scalar unit, and all
+// addressing is scalar: buffer loads / stores with a wave-uniform descriptor,
+// a constant lane offset and a scalar row offset.
+// Interior blocks of 16 ticks are branch-free and form their own loop; the
+// samples of the NEXT block are requested in one burst at the top of a block,
+// so every load has 16..31 ticks to land.
+// grid (ceil(C/BLK), G, W), block BLK;  needs L * C * 4 < 2^32
+// ---------------------------------------------------------------------------
+template <int W0, int W1, int W2, int W3>
+__global__ void __launch_bounds__(256, 2)
+k_colst_mask(const float* __restrict__ data, const double* __restrict__ med,
+             uint8_t* __restrict__ out, const int64_t* __restrict__ chunk_ends,
+             StFusedArgs fa, double thr_scale, int L, int C, int G, size_t ws_data,
+             size_t ws_out) {
+    constexpr int W[4] = {W0, W1, W2, W3};
+    constexpr int D[4] = {0, W0, W0 + W1, W0 + W1 + W2};   // ingest delay of stage j
+    constexpr int DOUT = D[3] + W3 - 1;                     // final flags lag the head by this
+    constexpr int MAXW = W3;
+    constexpr int UN = 16;                                   // ticks per unrolled block
+    static_assert(W0 <= W1 && W1 <= W2 && W2 <= W3 && W3 <= 8, "windows must be sorted, <= 8");
+    static_assert((W0 & (W0 - 1)) == 0 && (W1 & (W1 - 1)) == 0 && (W2 & (W2 - 1)) == 0 &&
+                  (W3 & (W3 - 1)) == 0, "power-of-two windows");
+    static_assert(W0 + W1 + W2 <= 7, "sample ring is 8 deep");
+    static_assert(DOUT < UN, "flag ring is 16 deep");
+
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int g = blockIdx.y;
+    const size_t win = blockIdx.z;
+    const int c0 = (int)chunk_ends[g], c1 = (int)chunk_ends[g + 1];
+    if (c1 <= c0) return;
+    const size_t Cs = (size_t)C;
+
+    float mad = (float)med[(win * Cs + c) * G + g];
+    float thr0 = isnan(mad) ? INFINITY : (float)((double)mad * thr_scale);
+    const int p0 = max(c0 - MAXW + 1, 0);
+    const int p1 = min(c1 + MAXW - 1, L);
+    const int Lp = p1 - p0;
+    const int o0 = c0 - p0, o1 = c1 - p0;   // output interior in padded coordinates
+    // Buffer addressing: a wave-uniform descriptor of the padded line block, a
+    // constant 32-bit lane offset and a scalar row offset -- no vector
+    // address arithmetic.
+    const unsigned rowb = (unsigned)C * 4u;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(data + win * ws_data + (size_t)p0 * Cs), 0, (int)((unsigned)Lp * rowb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(out + win * ws_out + (size_t)p0 * Cs), 0, (int)((unsigned)Lp * (unsigned)C), 0x00020000);
+    const int xoff = c * 4, ooff = c;
+    auto ldo = [&](int soff) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xoff, soff, 0));
+    };
+    auto ld = [&](int row) { return ldo((int)((unsigned)row * rowb)); };
+
+    // thr = f64(thr0) / rho^log2(w) (flagging.py:643); T = thr * w (exact)
+    double thr[4], T[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        thr[j] = (double)thr0 / fa.tf[j];
+        T[j] = thr[j] * (double)W[j];
+    }
+    double cum[4] = {0.0, 0.0, 0.0, 0.0};
+    double r0[W0], r1[W1], r2[W2], r3[W3];
+#pragma unroll
+    for (int k = 0; k < W0; k++) r0[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < W1; k++) r1[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < W2; k++) r2[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < W3; k++) r3[k] = 0.0;
+    uint64_t fP[UN], fN[UN], fA[UN];
+#pragma unroll
+    for (int k = 0; k < UN; k++) { fP[k] = 0; fN[k] = 0; fA[k] = 0; }
+    double xd[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) xd[k] = 0.0;
+
+    const int nticks = Lp + DOUT;
+    const int last = Lp - 1;
+    float nxt[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) nxt[u] = ld(min(u, last));
+
+    // interior blocks step two scalar byte offsets row by row; the empty asm
+    // keeps each step one s_add instead of 16 precomputed multiples
+    int xso = 0, oso = 0;
+    auto block = [&](auto fastc, const int base) {
+        constexpr bool fast = decltype(fastc)::value;
+        float cur[UN];
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            cur[u] = nxt[u];
+            if (fast) {
+                nxt[u] = ldo(xso);
+                xso += (int)rowb;
+                asm("" : "+s"(xso));
+            } else {
+                // edge blocks: rows past the end re-read the last row, never ingested
+                nxt[u] = ld(min(base + UN + u, last));
+            }
+        }
+        if (fast) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int PH = 0; PH < UN; PH++) {
+            const int n = base + PH;
+            xd[PH & 7] = (double)cur[PH];
+#pragma unroll
+            for (int j = 3; j >= 0; j--) {
+                const int w = W[j];
+                const int i = n - D[j];        // ingest position
+                if (fast || (i >= 0 && i < Lp)) {
+                    const int q = (PH - D[j]) & (UN - 1);
+                    const double x = xd[q & 7];
+                    double cl = x;
+                    if (j > 0) {
+                        const uint64_t cp = fP[q] & __builtin_amdgcn_ballot_w64(x > thr[j]);
+                        const uint64_t cn = fN[q] & __builtin_amdgcn_ballot_w64(x < -thr[j]);
+                        const bool m = __builtin_amdgcn_inverse_ballot_w64(cp | cn);
+                        cl = m ? __builtin_copysign(thr[j], x) : x;
+                    }
+                    const double cs = cum[j] + cl;
+                    cum[j] = cs;
+                    const int slot = (PH - D[j] + 1) & (w - 1);
+                    double old;
+                    if (j == 0) { old = r0[slot & (W0 - 1)]; r0[slot & (W0 - 1)] = cs; }
+                    else if (j == 1) { old = r1[slot & (W1 - 1)]; r1[slot & (W1 - 1)] = cs; }
+                    else if (j == 2) { old = r2[slot & (W2 - 1)]; r2[slot & (W2 - 1)] = cs; }
+                    else { old = r3[slot & (W3 - 1)]; r3[slot & (W3 - 1)] = cs; }
+                    const double S = cs - old;
+                    const bool full = fast || i + 1 - w >= 0;   // window complete
+                    if (j < 3) {
+                        uint64_t hp = __builtin_amdgcn_ballot_w64(S > T[j]);
+                        uint64_t hn = __builtin_amdgcn_ballot_w64(S < -T[j]);
+                        if (!full) { hp = 0; hn = 0; }
+                        // the first stage opens position q: plain assignment, so that
+                        // no mask of a recycled slot stays live around the loop
+                        if (j == 0) { fP[q] = hp; fN[q] = hn; }
+#pragma unroll
+                        for (int k = (j == 0 ? 1 : 0); k < w; k++) {
+                            fP[(q - k) & (UN - 1)] |= hp;
+                            fN[(q - k) & (UN - 1)] |= hn;
+                        }
+                    } else {
+                        // position q leaves the signed rings; later only the OR matters
+                        uint64_t h = __builtin_amdgcn_ballot_w64(__builtin_fabs(S) > T[j]);
+                        if (!full) h = 0;
+                        fA[q] = fP[q] | fN[q] | h;
+                        fP[q] = 0;
+                        fN[q] = 0;
+#pragma unroll
+                        for (int k = 1; k < w; k++) fA[(q - k) & (UN - 1)] |= h;
+                    }
+                }
+            }
+            const int ef = n - DOUT;
+            const int fs = (PH - DOUT) & (UN - 1);
+            if (fast) {
+                const bool f = __builtin_amdgcn_inverse_ballot_w64(fA[fs]);
+                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(f ? 1 : 0), ors, ooff, oso, 0);
+                oso += C;
+                asm("" : "+s"(oso));
+            } else if (ef >= o0 && ef < o1) {
+                const bool f = __builtin_amdgcn_inverse_ballot_w64(fA[fs]);
+                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(f ? 1 : 0), ors, ooff, (int)((unsigned)ef * (unsigned)C), 0);
+            }
+            fA[fs] = 0;
+            // keep every tick's store (and the scalar chains) in its own scheduling region
+            if (fast) __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // head (edge-checked) blocks, then the branch-free interior as its own
+    // counted loop (its register assignment is not tied to the edge code),
+    // then the edge-checked tail
+    auto is_fast = [&](int base) {
+        return base >= UN && base + 2 * UN - 1 < Lp && base - DOUT >= o0 && base + UN - 1 - DOUT < o1;
+    };
+    int base = 0;
+    for (; base < nticks && !is_fast(base); base += UN) block(std::false_type{}, base);
+    int nfast = 0;
+    for (int b = base; b < nticks && is_fast(b); b += UN) nfast++;
+    xso = (int)((unsigned)(base + UN) * rowb);
+    oso = (int)((unsigned)(base - DOUT) * (unsigned)C);
+    for (int b = 0; b < nfast; b++) block(std::true_type{}, 0);   // interior blocks do not use base
+    base += nfast * UN;
+    for (; base < nticks; base += UN) block(std::false_type{}, base);
+}

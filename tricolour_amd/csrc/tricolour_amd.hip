@@ -330,6 +330,17 @@ bool st_use_fused(const StWin& sw) {
     return sw.nw == 4 && sw.w[0] == 1 && sw.w[1] == 2 && sw.w[2] == 4 && sw.w[3] == 8;
 }
 
+// The lane-mask cascade (K7c) addresses a window through 32-bit buffer
+// offsets; larger windows and TRI_ST_REGISTER=1 (tests) take the register
+// cascade (K7b).
+bool st_use_mask(int L, int C) {
+    static const bool force_register = [] {
+        const char* e = getenv("TRI_ST_REGISTER");
+        return e && e[0] == '1';
+    }();
+    return !force_register && (uint64_t)L * (uint64_t)C * 4u < (1ull << 32);
+}
+
 int launch_median(const Run& r, const float* data, const uint8_t* flags, double* med, size_t WSd,
                   size_t WSf, size_t RS, size_t ES, const int64_t* seg_start,
                   const int64_t* seg_len, int R, int G, int64_t W, int64_t max_len, bool vec_ok = false,
@@ -526,8 +537,12 @@ int launch_colst(const Run& r, const StWin& sw, const float* data, const double*
     if (st_use_fused(sw)) {
         StFusedArgs fa;
         for (int j = 0; j < 4; j++) fa.tf[j] = sw.tf[j];
-        hipLaunchKernelGGL((k_colst_fused<1, 2, 4, 8>), grid, dim3(blk), 0, r.st, data, med, out,
-                           d_chunk_ends, fa, thr_scale, L, C, G, ws_data, ws_out);
+        if (st_use_mask(L, C))
+            hipLaunchKernelGGL((k_colst_mask<1, 2, 4, 8>), grid, dim3(blk), 0, r.st, data, med, out,
+                               d_chunk_ends, fa, thr_scale, L, C, G, ws_data, ws_out);
+        else
+            hipLaunchKernelGGL((k_colst_fused<1, 2, 4, 8>), grid, dim3(blk), 0, r.st, data, med, out,
+                               d_chunk_ends, fa, thr_scale, L, C, G, ws_data, ws_out);
     } else {
         hipLaunchKernelGGL(k_colst_dyn, grid, dim3(blk), 0, r.st, data, med, out, r.ws.ring, r.ws.acc,
                            d_chunk_ends, sw, thr_scale, L, C, G, ws_data, ws_out);
@@ -1129,13 +1144,18 @@ extern "C" int tri_bench_sumthreshold(const float* data, const double* mad, uint
     dim3 grid((unsigned)cdiv(C, blk), 1, (unsigned)n_win);
     size_t ws = (size_t)n_line * n_col;
     bool can_fuse = sw.nw == 4 && sw.w[0] == 1 && sw.w[1] == 2 && sw.w[2] == 4 && sw.w[3] == 8;
-    if (variant == 2 && !can_fuse) return set_err(TRI_EUNSUPPORTED, "register cascade needs windows (1,2,4,8)");
-    bool fused = variant == 2 || (variant == 0 && can_fuse);
+    if ((variant == 2 || variant == 3) && !can_fuse) return set_err(TRI_EUNSUPPORTED, "register cascade needs windows (1,2,4,8)");
+    if (variant == 3 && !((uint64_t)L * (uint64_t)C * 4u < (1ull << 32)))
+        return set_err(TRI_EUNSUPPORTED, "lane-mask cascade needs a window below 2^32 bytes");
+    if (variant == 0 && can_fuse) variant = st_use_mask(L, C) ? 3 : 2;
+    bool fused = variant == 2;
     StFusedArgs fa;
     for (int j = 0; j < 4; j++) fa.tf[j] = sw.tf[j < sw.nw ? j : 0];
     HIPCHK(hipEventRecord(e0, st));
     for (int i = 0; i < repeats; i++) {
-        if (fused)
+        if (variant == 3)
+            hipLaunchKernelGGL((k_colst_mask<1, 2, 4, 8>), grid, dim3(blk), 0, st, data, mad, out, d_ends, fa, thr_scale, L, C, 1, ws, ws);
+        else if (fused)
             hipLaunchKernelGGL((k_colst_fused<1, 2, 4, 8>), grid, dim3(blk), 0, st, data, mad, out, d_ends, fa, thr_scale, L, C, 1, ws, ws);
         else
             hipLaunchKernelGGL(k_colst_dyn, grid, dim3(blk), 0, st, data, mad, out, ring, acc, d_ends, sw, thr_scale, L, C, 1, ws, ws);
