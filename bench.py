@@ -120,12 +120,12 @@ def cpu_baseline(kw, T, F, seconds_budget=25.0):
                        "reference numba path (oracle/), OpenMP over windows" % (nwin, T, F, dt))
 
 
-def roofline_sumthreshold(torch, device, T, F, kw):
-    """Times the fused SumThreshold column kernel alone (time-axis geometry:
-    line = time, coalesced columns = channels) with HIP events on its stream."""
+def roofline_sumthreshold(torch, device, T, F, kw, nwin):
+    """Times the fused SumThreshold column kernel alone, in the launch geometry
+    of the step's time-axis pass (line = time, coalesced columns = channels, all
+    `nwin` windows of the slab in one launch), with HIP events on its stream."""
     from tricolour_amd import _lib
     lib = _lib.lib()
-    nwin = 64
     g = torch.Generator(device=device)
     g.manual_seed(7)
     data = torch.randn((nwin, T, F), generator=g, device=device)
@@ -136,7 +136,7 @@ def roofline_sumthreshold(torch, device, T, F, kw):
     warr = (C.c_int64 * len(wins))(*[int(w) for w in wins])
     ms = C.c_float(0)
     stream = torch.cuda.current_stream(device).cuda_stream
-    for reps in (2, 10):
+    for reps in (2, 8):
         _lib.check(lib.tri_bench_sumthreshold(data.data_ptr(), mad.data_ptr(), out.data_ptr(),
                                               nwin, T, F, warr, len(wins),
                                               float(kw.get("outlier_nsigma", 4.5)),
@@ -270,7 +270,7 @@ def main():
         flagging.release_workspace()
         torch.cuda.empty_cache()
         if not args.no_roofline:
-            res["roofline"] = roofline_sumthreshold(torch, device, T, F, kw)
+            res["roofline"] = roofline_sumthreshold(torch, device, T, F, kw, min(args.bl * args.corr, 1008))
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(kw, T, F)
         print(json.dumps(res))
