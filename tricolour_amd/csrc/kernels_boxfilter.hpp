@@ -454,21 +454,36 @@ k_colfilter_lds_t(const float* __restrict__ srcW, const float* __restrict__ srcO
 // K4c  "Lane-per-stage" form of the single-sweep box filter for medium radii
 // (the four 2r-deep delay lines of K4b no longer fit LDS at useful occupancy):
 // the four cascade stages of one line run in the four lanes of a quad, every
-// thread owning ONE stage and ONE LDS ring (2r floats), so the same LDS holds
-// four times the threads.  Stage p takes its input from lane p-1's output of
-// the previous step (DPP quad shuffle); the quad's four lanes prefetch four
+// thread owning ONE stage and ONE LDS delay line, so the same LDS holds four
+// times the threads.  Stage p takes its input from lane p-1's output of the
+// previous step (DPP quad shuffle); the quad's four lanes prefetch four
 // consecutive line positions per load instruction and the stage-0 lane picks
 // them up by DPP broadcast.  Arithmetic per stage is identical to K4b (same
 // causal running sums, same order) -- only the thread that executes a stage
 // differs.  One wave (16 lines) per workgroup; no barriers.
-// grid (ceil(C/16), W, 2 images), block 64, dynamic LDS 2r * 64 floats
+//   * The delay lines are indexed by the wave's step counter m (write slot
+//     m mod Rc, read slot (m - 2r) mod Rc, Rc = 2r rounded up to a multiple of
+//     32), so every LDS address is lane offset + wave-uniform offset, and the
+//     32 trailing samples of a block of steps are read in one burst before the
+//     block's writes (none of them can hit a slot read later in the block).
+//   * Every lane updates its running sum at every step (inputs outside a
+//     stage's range are zero, which leaves the float64 sum unchanged), so only
+//     the stores are range-checked, and interior blocks run without predicates.
+//   * The last stage's outputs are handed round the quad: lane p keeps the
+//     output of step 4k + p, and every fourth step all 64 lanes divide (when
+//     the denominators are not deferred) and store one value each -- four
+//     consecutive rows of the quad's line.
+// grid (ceil(C/16), W, 2 images), block 64, dynamic LDS Rc * 64 floats (+ tile)
 // ---------------------------------------------------------------------------
 template <int CTRL>
 __device__ __forceinline__ float dpp_quad(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+    // every lane of a quad_perm has a valid source lane: no fill value needed
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, false));
 }
 // quad_perm(a,b,c,d): lane i of each quad reads lane {a,b,c,d}[i]
 #define QUAD_PERM(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
+
+__host__ __device__ inline int lane4_ring_capacity(int r) { return (2 * r + 31) / 32 * 32; }
 
 template <int SRCMODE, bool DIV>
 __global__ void __launch_bounds__(64)
@@ -481,10 +496,11 @@ k_colfilter_lane4(const float* __restrict__ srcW, const float* __restrict__ srcO
     const int p = lane & 3;                         // cascade stage of this lane
     const int c = blockIdx.x * 16 + (lane >> 2);
     const bool colok = c < C;
+    const bool colok_wave = (int)blockIdx.x * 16 + 16 <= C;   // all 16 lines of the wave exist
     const int cc = colok ? c : C - 1;               // out-of-range quads compute on a valid column, store nothing
     const size_t win = blockIdx.y;
     const int img = blockIdx.z;
-    const int R2 = 2 * r;
+    const int R2 = 2 * r;                           // >= 32 (host: r > LDS_R_MAX)
     const size_t Cs = (size_t)C;
     const float* src = SRCMODE == 1 ? ((img == 0 ? srcW : srcO) + win * sws_img + cc) : nullptr;
     // SRCMODE 3: input images stored transposed (line c = row c of a [C][ld]
@@ -495,13 +511,13 @@ k_colfilter_lane4(const float* __restrict__ srcW, const float* __restrict__ srcO
     const float* sd = (SRCMODE == 0 || SRCMODE == 2) ? srcData + win * sws + cc : nullptr;
     const unsigned* sf4 = SRCMODE == 2 ? reinterpret_cast<const unsigned*>(srcFlags) + win * (sws / 4) + cc : nullptr;
     float* dst = (img == 0 ? dstW : dstO) + win * dws + cc;
+    const int Rc = lane4_ring_capacity(r);
     float* ring = cf_ring + lane;                   // slot k at ring[k * 64]
-    float* tile = cf_ring + (size_t)R2 * 64;        // SRCMODE 3: [32 positions][16 lines + 1]
-    for (int k = 0; k < R2; k++) ring[k * 64] = 0.0f;
+    float* tile = cf_ring + (size_t)Rc * 64;        // SRCMODE 3: [32 positions][16 lines + 1]
+    for (int k = 0; k < Rc; k++) ring[k * 64] = 0.0f;
 
-    // per-stage ranges (see K4b): stage p runs for t in [0, tend); its input is
-    // the upstream value for t in [ilo, ihi), zero otherwise
-    const int tend = (p == 0) ? n + R2 : n + 4 * r;
+    // per-stage input range (see K4b): stage p takes the upstream value for its
+    // time index t = m - p in [ilo, ihi), zero otherwise
     const int ilo = (p == 3) ? R2 : 0;
     const int ihi = (p == 0) ? n : ((p == 1) ? n + R2 : n + 4 * r);
 
@@ -534,10 +550,10 @@ k_colfilter_lane4(const float* __restrict__ srcW, const float* __restrict__ srcO
 
     double s = 0.0;
     float o_last = 0.0f;                            // this stage's output of the previous step
-    int slot = 0;
-    float old = 0.0f;
+    float omine = 0.0f;                             // last-stage output kept by this lane
     const int total = n + 4 * r + 3;
-    for (int m0 = 0; m0 < total; m0 += PF) {
+    auto block = [&](auto fastc, const int m0) {
+        constexpr bool fast = decltype(fastc)::value;
 #pragma unroll
         for (int q = 0; q < PF / 4; q++) {
             if (SRCMODE == 2) {
@@ -558,10 +574,19 @@ k_colfilter_lane4(const float* __restrict__ srcW, const float* __restrict__ srcO
             __syncthreads();
         }
         issue(m0 + PF);
+        // trailing samples of the 32 steps (written 2r steps ago), in one burst
+        const int wp0 = m0 % Rc;                    // multiple of 32: no wrap inside the block
+        int rp = (m0 + 8 * Rc - R2) % Rc;
+        float oldv[PF];
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            oldv[u] = ring[rp * 64];
+            rp = (rp + 1 == Rc) ? 0 : rp + 1;
+        }
+        float* wr = ring + wp0 * 64;
 #pragma unroll
         for (int u = 0; u < PF; u++) {
             const int m = m0 + u;
-            const int t = m - p;                    // this stage's time index
             // sample for stage 0: position m was loaded by lane (u & 3) of the quad
             float xs;
             if (SRCMODE == 3) xs = tile[u * 17 + (lane >> 2)];
@@ -571,25 +596,30 @@ k_colfilter_lane4(const float* __restrict__ srcW, const float* __restrict__ srcO
             else xs = dpp_quad<QUAD_PERM(3, 3, 3, 3)>(cur[u >> 2]);
             // upstream stage's previous output
             const float up = dpp_quad<QUAD_PERM(0, 0, 1, 2)>(o_last);
-            const bool act = t >= 0 && t < tend;
             float in = (p == 0) ? xs : up;
-            in = (t >= ilo && t < ihi) ? in : 0.0f;
-            const int ns = (slot + 1 == R2) ? 0 : slot + 1;
-            const float nold = ring[ns * 64];       // next step's trailing sample (R2 >= 2)
-            if (act) {
-                ring[slot * 64] = in;
-                s += (double)in;
-                o_last = (float)s;
-                s -= (double)old;
-                old = nold;
-                slot = ns;
-                if (p == 3) {
-                    const int i = t - 4 * r;
-                    if (i >= 0 && colok) dst[(size_t)i * Cs] = DIV ? o_last / denom : o_last;
-                }
+            if (!fast) {
+                const int t = m - p;                // this stage's time index
+                in = (t >= ilo && t < ihi) ? in : 0.0f;
+            }
+            wr[u * 64] = in;
+            s += (double)in;
+            o_last = (float)s;
+            s -= (double)oldv[u];
+            // the quad's lane 3 holds the filter output of line position m - 3 - 4r
+            const float cap = dpp_quad<QUAD_PERM(3, 3, 3, 3)>(o_last);
+            omine = ((u & 3) == p) ? cap : omine;
+            if ((u & 3) == 3) {
+                const int i = m - 6 + p - 4 * r;    // lane p kept step m - 3 + p
+                if (fast || (i >= 0 && i < n && colok)) dst[(size_t)i * Cs] = DIV ? omine / denom : omine;
             }
         }
         if (SRCMODE == 3) __syncthreads();          // tile fully consumed before it is rewritten
+    };
+    for (int m0 = 0; m0 < total; m0 += PF) {
+        // interior: every stage inside its input range, every store inside the line
+        const bool fast = colok_wave && m0 >= 4 * r + 6 && m0 + PF <= n;
+        if (fast) block(std::true_type{}, m0);
+        else block(std::false_type{}, m0);
     }
 }
 

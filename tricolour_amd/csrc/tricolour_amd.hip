@@ -431,7 +431,7 @@ int launch_colfilter(const Run& r, int srcmode, float* bufW, float* bufO, const 
     int bt = colfilter_lds_block(rad, C);
     if (deferred_denom) *deferred_denom = 0.0f;
     if (bt > 0 && colfilter_use_lane4(rad) && !transposed_out) {
-        size_t lds = (size_t)2 * rad * 64 * sizeof(float);
+        size_t lds = (size_t)lane4_ring_capacity(rad) * 64 * sizeof(float);
         dim3 grid((unsigned)cdiv(C, 16), (unsigned)W, 2);
         // thread-safe one-time setup (C++11 static initialisation)
         static const hipError_t attr4 = [] {
@@ -642,7 +642,7 @@ bool colfilter_t4_usable(int rad) {
 int launch_colfilter_t4(const Run& r, const float* srcW, const float* srcO, float* dstW, float* dstO,
                         int n, int C, int ld, int rad, size_t sws_img, size_t dws, int64_t W, float* deferred_denom) {
     float denom = box_denominator(rad);
-    size_t lds = ((size_t)2 * rad * 64 + 32 * 17) * sizeof(float);
+    size_t lds = ((size_t)lane4_ring_capacity(rad) * 64 + 32 * 17) * sizeof(float);
     static const hipError_t attr = [] {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lane4<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lane4<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
