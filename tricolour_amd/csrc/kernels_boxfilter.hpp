@@ -483,6 +483,9 @@ __device__ __forceinline__ float dpp_quad(float v) {
 // quad_perm(a,b,c,d): lane i of each quad reads lane {a,b,c,d}[i]
 #define QUAD_PERM(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
 
+#ifndef LANE4_SKEW
+#define LANE4_SKEW 2
+#endif
 __host__ __device__ inline int lane4_ring_capacity(int r) { return (2 * r + 31) / 32 * 32; }
 
 template <int SRCMODE, bool DIV>
@@ -548,10 +551,17 @@ k_colfilter_lane4(const float* __restrict__ srcW, const float* __restrict__ srcO
     };
     issue(0);
 
+    // Stage p runs SK steps behind stage p-1 (time index t = m - SK p) and takes
+    // the upstream output of SK steps ago: consecutive steps are then tied only
+    // by the running sum (two float64 adds), not by shuffle -> select ->
+    // convert -> add -> convert through the quad.
+    constexpr int SK = LANE4_SKEW;
     double s = 0.0;
-    float o_last = 0.0f;                            // this stage's output of the previous step
+    float oh[SK];                                   // this stage's outputs of the last SK steps
+#pragma unroll
+    for (int k = 0; k < SK; k++) oh[k] = 0.0f;
     float omine = 0.0f;                             // last-stage output kept by this lane
-    const int total = n + 4 * r + 3;
+    const int total = n + 4 * r + 3 * SK;
     auto block = [&](auto fastc, const int m0) {
         constexpr bool fast = decltype(fastc)::value;
 #pragma unroll
@@ -594,22 +604,23 @@ k_colfilter_lane4(const float* __restrict__ srcW, const float* __restrict__ srcO
             else if ((u & 3) == 1) xs = dpp_quad<QUAD_PERM(1, 1, 1, 1)>(cur[u >> 2]);
             else if ((u & 3) == 2) xs = dpp_quad<QUAD_PERM(2, 2, 2, 2)>(cur[u >> 2]);
             else xs = dpp_quad<QUAD_PERM(3, 3, 3, 3)>(cur[u >> 2]);
-            // upstream stage's previous output
-            const float up = dpp_quad<QUAD_PERM(0, 0, 1, 2)>(o_last);
+            // upstream stage's output of SK steps ago
+            const float up = dpp_quad<QUAD_PERM(0, 0, 1, 2)>(oh[u % SK]);
             float in = (p == 0) ? xs : up;
             if (!fast) {
-                const int t = m - p;                // this stage's time index
+                const int t = m - SK * p;           // this stage's time index
                 in = (t >= ilo && t < ihi) ? in : 0.0f;
             }
             wr[u * 64] = in;
             s += (double)in;
-            o_last = (float)s;
+            const float o_new = (float)s;
+            oh[u % SK] = o_new;
             s -= (double)oldv[u];
-            // the quad's lane 3 holds the filter output of line position m - 3 - 4r
-            const float cap = dpp_quad<QUAD_PERM(3, 3, 3, 3)>(o_last);
+            // the quad's lane 3 holds the filter output of line position m - 3 SK - 4r
+            const float cap = dpp_quad<QUAD_PERM(3, 3, 3, 3)>(o_new);
             omine = ((u & 3) == p) ? cap : omine;
             if ((u & 3) == 3) {
-                const int i = m - 6 + p - 4 * r;    // lane p kept step m - 3 + p
+                const int i = m - 3 + p - 3 * SK - 4 * r;   // lane p kept step m - 3 + p
                 if (fast || (i >= 0 && i < n && colok)) dst[(size_t)i * Cs] = DIV ? omine / denom : omine;
             }
         }
@@ -617,7 +628,7 @@ k_colfilter_lane4(const float* __restrict__ srcW, const float* __restrict__ srcO
     };
     for (int m0 = 0; m0 < total; m0 += PF) {
         // interior: every stage inside its input range, every store inside the line
-        const bool fast = colok_wave && m0 >= 4 * r + 6 && m0 + PF <= n;
+        const bool fast = colok_wave && m0 >= 4 * r + 3 * SK && m0 + PF <= n;
         if (fast) block(std::true_type{}, m0);
         else block(std::false_type{}, m0);
     }

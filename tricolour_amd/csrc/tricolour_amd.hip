@@ -380,8 +380,15 @@ int launch_median(const Run& r, const float* data, const uint8_t* flags, double*
 // Radius limits of the single-sweep kernels.  r <= LDS_R_MAX: K4b with 256
 // threads (4 rings per thread); r <= LANE4_R_MAX: K4c (one ring per thread);
 // beyond: the in-place multi-pass kernel.
-#define LDS_R_MAX 20   // measured: 4 rings per thread win up to here (256 threads to r = 10, 128 beyond)
-#define LANE4_R_MAX 80
+// Measured crossovers (scripts/build_variants.sh -DLDS_R_MAX=.. -DLANE4_R_MAX=..): four rings per thread win
+// up to r = 15 (256 threads to r = 10, 128 beyond; K4c needs 2r >= 32 anyway), one ring per thread up to
+// r = 160 (two waves per CU), the multi-pass kernel beyond.
+#ifndef LDS_R_MAX
+#define LDS_R_MAX 15
+#endif
+#ifndef LANE4_R_MAX
+#define LANE4_R_MAX 160
+#endif
 int colfilter_lds_block(int rad, int C) {
     static const bool disabled = [] {
         const char* e = getenv("TRI_FILTER_MULTIPASS");
@@ -393,7 +400,7 @@ int colfilter_lds_block(int rad, int C) {
     }();
     if (disabled || rad <= 0) return 0;
     if (no_lane4) {
-        int bt = rad <= 10 ? 256 : (rad <= 20 ? 128 : (rad <= 40 ? 64 : 0));
+        int bt = rad <= 10 ? 256 : (rad <= 20 ? 128 : (rad <= 40 ? 64 : 0));   // K4b alone (TRI_FILTER_NO_LANE4)
         while (bt > 64 && bt / 2 >= C) bt /= 2;
         return bt;
     }
@@ -633,7 +640,7 @@ int launch_colfilter_t(const Run& r, const float* srcW, const float* srcO, float
     return TRI_OK;
 }
 
-// Lane-per-stage variant of the same (radii 17..80): k_colfilter_lane4<3, *>.
+// Lane-per-stage variant of the same (radii 17..LANE4_R_MAX): k_colfilter_lane4<3, *>.
 bool colfilter_t4_usable(int rad) {
     static const bool off = [] { const char* e = getenv("TRI_FILTER_NO_TIN"); return e && e[0] == '1'; }();
     return !off && colfilter_use_lane4(rad);
