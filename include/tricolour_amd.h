@@ -156,6 +156,20 @@ int tri_unpack_data(const uint8_t *flag_windows,
                     uint8_t *out_flags, int any_corr, void *stream);
 
 /*
+ * Flag counts behind tricolour.window_statistics._window_stats
+ * (window_statistics.py:12-66): one pass over a (bl, corr, time, chan) uint8
+ * flag window gives
+ *   per_bl[bl]     number of set flags of baseline bl     (per-antenna,
+ *                  per-baseline, per-scan and per-field sums, :27-53)
+ *   per_chan[chan] number of set flags of channel chan    (per-ddid frequency
+ *                  bins, :55-66)
+ * Both outputs are device arrays of uint64 and are zeroed by the call.
+ */
+int tri_window_counts(const uint8_t *flags, int64_t nbl, int64_t ncorr,
+                      int64_t ntime, int64_t nchan, uint64_t *per_bl,
+                      uint64_t *per_chan, void *stream);
+
+/*
  * Replaces tricolour.flagging.flag_nans_and_zeros (flagging.py:29-62):
  * out = (vis == 0) | isnan(vis) | (flags != 0), elementwise over n samples.
  */

@@ -423,3 +423,49 @@ def uvcontsub_flagger(vis, flags, major_cycles=5, or_original_from_cycle=1,
                 new = absres > sigma * mad
                 res[cp] = (start[cp] | new) if mi >= or_original_from_cycle else new
     return res.reshape(nbl, ncorr, ntime, nfreq)
+
+
+# ---- flag summary statistics (numpy restatement) ----------
+
+def window_counts(flag_window):
+    """per-baseline and per-channel numbers of set flags of a (bl, corr, time,
+    chan) window: the two reductions every tally of window_statistics.py:12-66
+    decomposes into."""
+    fw = np.asarray(flag_window) != 0
+    return (fw.sum(axis=(1, 2, 3), dtype=np.uint64), fw.sum(axis=(0, 1, 2), dtype=np.uint64))
+
+
+def window_stats_block(flag_window, ubls, chan_freqs, antenna_names, scan_no,
+                       field_name, ddid, nchanbins=10):
+    """Restates `_window_stats` (window_statistics.py:12-66) with the same
+    masked reductions over the whole window as the reference; returns plain
+    dicts  {"counts_per_ant": {...}, "size_per_ant": {...}, ...}."""
+    fw = np.asarray(flag_window)
+    ubls = np.asarray(ubls)
+    chan_freqs = np.asarray(chan_freqs)
+    res = {k: {} for k in ("counts_per_ant", "size_per_ant", "counts_per_bl", "size_per_bl",
+                           "counts_per_field", "size_per_field", "counts_per_scan", "size_per_scan",
+                           "counts_per_ddid", "bins_per_ddid", "size_per_ddid")}
+    for ai, a in enumerate(antenna_names):                                   # :27-32
+        sel = np.logical_or(ubls[:, 1] == ai, ubls[:, 2] == ai)
+        res["counts_per_ant"][a] = int(np.sum(fw[sel], dtype=np.uint64))
+        res["size_per_ant"][a] = int(fw[sel].size)
+    for b in np.unique(ubls[:, 0]):                                          # :35-43
+        sel = ubls[:, 0] == b
+        name = "%s&%s" % (antenna_names[ubls[sel, 1][0]], antenna_names[ubls[sel, 2][0]])
+        res["counts_per_bl"][name] = res["counts_per_bl"].get(name, 0) + int(np.sum(fw[sel], dtype=np.uint64))
+        res["size_per_bl"][name] = res["size_per_bl"].get(name, 0) + int(fw[sel].size)
+    total = int(np.sum(fw, dtype=np.uint64))                                 # :46-52
+    res["counts_per_field"][field_name] = total
+    res["size_per_field"][field_name] = int(fw.size)
+    res["counts_per_scan"][scan_no] = total
+    res["size_per_scan"][scan_no] = int(fw.size)
+    edges = np.linspace(np.min(chan_freqs), np.max(chan_freqs), nchanbins)   # :55-62
+    bins = np.zeros(nchanbins, dtype=np.uint32)
+    for i in range(nchanbins - 1):
+        sel = np.logical_and(chan_freqs >= edges[i], chan_freqs < edges[i + 1])
+        bins[i] = np.sum(fw[:, :, :, sel], dtype=np.uint64)
+    res["counts_per_ddid"][ddid] = bins.astype(np.uint64)
+    res["bins_per_ddid"][ddid] = edges
+    res["size_per_ddid"][ddid] = int(fw.size)
+    return res

@@ -110,6 +110,8 @@ _SIGNATURES = {
     "tri_flag_nans_and_zeros": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "tri_apply_baseline_channel_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                                   C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
+    "tri_window_counts": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     "tri_uvcontsub_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
     "tri_uvcontsub_flagger": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                         C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_void_p, C.c_size_t,

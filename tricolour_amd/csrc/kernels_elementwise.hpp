@@ -791,3 +791,74 @@ __global__ void k_uv_apply(const float* __restrict__ absres, const double* __res
     uint8_t old = rflags[cp * N + i];
     rflags[cp * N + i] = do_or ? (uint8_t)((old || nf) ? 1 : 0) : (uint8_t)(nf ? 1 : 0);
 }
+
+// ---------------------------------------------------------------------------
+// Flag counts of a (bl, corr, time, chan) window for the flag summary
+// (window_statistics.py:12-66): every per-antenna / per-baseline / per-scan /
+// per-field number of the reference is a sum of per-baseline counts, every
+// per-channel-bin number a sum of per-channel counts, so one pass produces
+//   per_bl[bl]     = # of set flags of baseline bl
+//   per_chan[chan] = # of set flags of channel chan over bl, corr, time
+// A block owns ROWS rows of one baseline and a tile of 4 * 256 channels; a
+// thread counts four adjacent channels from 32-bit loads (VEC) or one channel
+// (scalar fallback), then adds its column counts to per_chan and, through a
+// wave + block reduction, its total to per_bl.
+// grid (ceil(nchan / (VEC ? 1024 : 256)), ceil(rows / ROWS), nbl), block 256
+// ---------------------------------------------------------------------------
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+k_window_counts(const uint8_t* __restrict__ flags, unsigned long long* __restrict__ per_bl,
+                unsigned long long* __restrict__ per_chan, int rows, int nchan, int rows_per_block) {
+    __shared__ unsigned long long part[4];
+    const int bl = blockIdx.z;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(r0 + rows_per_block, rows);
+    const uint8_t* base = flags + ((size_t)bl * rows + r0) * (size_t)nchan;
+    unsigned long long mine = 0;
+    if (VEC) {
+        const int c4 = blockIdx.x * 256 + threadIdx.x;          // group of four channels
+        if (c4 * 4 < nchan) {
+            const unsigned* row = reinterpret_cast<const unsigned*>(base) + c4;
+            const size_t stride = (size_t)nchan / 4;
+            unsigned cnt[4] = {0, 0, 0, 0};
+            unsigned acc = 0;                                    // four byte counters
+            int held = 0;
+            for (int r = r0; r < r1; r++, row += stride) {
+                unsigned w = *row;
+                // bytes != 0 -> 1 (flags are 0/1, anything else still counts once)
+                unsigned t = ((w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w;
+                acc += (t >> 7) & 0x01010101u;
+                if (++held == 255) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) cnt[k] += (acc >> (8 * k)) & 0xFFu;
+                    acc = 0;
+                    held = 0;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                cnt[k] += (acc >> (8 * k)) & 0xFFu;
+                if (cnt[k]) atomicAdd(&per_chan[(size_t)c4 * 4 + k], (unsigned long long)cnt[k]);
+                mine += cnt[k];
+            }
+        }
+    } else {
+        const int c = blockIdx.x * 256 + threadIdx.x;
+        if (c < nchan) {
+            unsigned cnt = 0;
+            const uint8_t* q = base + c;
+            for (int r = r0; r < r1; r++, q += nchan) cnt += (*q != 0) ? 1u : 0u;
+            if (cnt) atomicAdd(&per_chan[c], (unsigned long long)cnt);
+            mine = cnt;
+        }
+    }
+    // block total -> per_bl
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long tot = part[0] + part[1] + part[2] + part[3];
+        if (tot) atomicAdd(&per_bl[bl], tot);
+    }
+}

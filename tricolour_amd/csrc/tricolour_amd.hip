@@ -1255,6 +1255,33 @@ extern "C" int tri_flag_nans_and_zeros(const void* vis, int vis_dtype, const uin
     return TRI_OK;
 }
 
+extern "C" int tri_window_counts(const uint8_t* flags, int64_t nbl, int64_t ncorr, int64_t ntime,
+                                 int64_t nchan, uint64_t* per_bl, uint64_t* per_chan, void* stream) {
+    if (!per_bl || !per_chan) return set_err(TRI_EINVAL, "NULL pointer argument");
+    if (nbl < 0 || ncorr < 0 || ntime < 0 || nchan < 0) return set_err(TRI_EINVAL, "bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    if (nbl > 0) HIPCHK(hipMemsetAsync(per_bl, 0, (size_t)nbl * sizeof(uint64_t), st));
+    if (nchan > 0) HIPCHK(hipMemsetAsync(per_chan, 0, (size_t)nchan * sizeof(uint64_t), st));
+    const int64_t rows = ncorr * ntime;
+    if (nbl == 0 || rows == 0 || nchan == 0) return TRI_OK;
+    if (!flags) return set_err(TRI_EINVAL, "NULL pointer argument");
+    if (nbl > 65535 || rows >= (1ll << 31) || nchan >= (1ll << 31)) return set_err(TRI_EUNSUPPORTED, "window too large for one call");
+    // enough row chunks per baseline to fill the device, at most 65535
+    int rows_per_block = 256;
+    while (cdiv(rows, rows_per_block) > 65535) rows_per_block *= 2;
+    const bool vec = nchan % 4 == 0 && ((uintptr_t)flags % 4 == 0);
+    dim3 grid((unsigned)cdiv(nchan, vec ? 1024 : 256), (unsigned)cdiv(rows, rows_per_block), (unsigned)nbl);
+    static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "64-bit counters");
+    if (vec)
+        hipLaunchKernelGGL(k_window_counts<true>, grid, dim3(256), 0, st, flags, (unsigned long long*)per_bl,
+                           (unsigned long long*)per_chan, (int)rows, (int)nchan, rows_per_block);
+    else
+        hipLaunchKernelGGL(k_window_counts<false>, grid, dim3(256), 0, st, flags, (unsigned long long*)per_bl,
+                           (unsigned long long*)per_chan, (int)rows, (int)nchan, rows_per_block);
+    LAUNCHCHK();
+    return TRI_OK;
+}
+
 extern "C" int tri_apply_baseline_channel_mask(const uint8_t* flags, uint8_t* out_flags,
                                                const uint8_t* bl_sel, const uint8_t* chan_mask,
                                                int mode, int64_t nbl, int64_t ncorr, int64_t ntime,
