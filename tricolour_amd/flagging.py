@@ -116,6 +116,24 @@ def _pick_batch(lib, p, n_cp, T, F, budget):
     return lo, lib.tri_workspace_bytes(lo, T, F, C.byref(p))
 
 
+def _host_call_stream(torch, vis, flags):
+    """Calls that hand over HOST arrays (the dask graph does) run on a stream of
+    their own, one per calling thread: the H2D copies, kernels and the D2H copy
+    of blocks processed by different threads then overlap instead of queueing
+    on the default stream.  Device tensors stay on the caller's current stream."""
+    for a in (vis, flags):
+        if torch.is_tensor(a) and a.is_cuda:
+            return None
+    device = torch.device("cuda", torch.cuda.current_device())
+    streams = getattr(_tls, "streams", None)
+    if streams is None:
+        streams = _tls.streams = {}
+    key = device.index
+    if key not in streams:
+        streams[key] = torch.cuda.Stream(device)
+    return streams[key]
+
+
 def _as_device_inputs(torch, vis, flags):
     """Returns (vis_tensor, flags_u8_tensor, vis_dtype_code, from_numpy)."""
     from_numpy = isinstance(vis, np.ndarray) or isinstance(flags, np.ndarray)
@@ -190,6 +208,15 @@ def sum_threshold_flagger(vis, flags, outlier_nsigma=4.5,
                        average_freq, flag_all_time_frac, flag_all_freq_frac, rho,
                        num_major_iterations)
     torch = _require_gpu()
+    side = _host_call_stream(torch, vis, flags)
+    if side is not None:
+        with torch.cuda.stream(side):
+            return _flag_on_current_stream(torch, lib, p, vis, flags, average_freq, _debug)
+    return _flag_on_current_stream(torch, lib, p, vis, flags, average_freq, _debug)
+
+
+def _flag_on_current_stream(torch, lib, p, vis, flags, average_freq, _debug):
+    nbl, ncorr, ntime, nchan = (int(s) for s in vis.shape)
     v, f8, code, from_numpy, device = _as_device_inputs(torch, vis, flags)
     if code == -64:
         if int(average_freq) != 1:
