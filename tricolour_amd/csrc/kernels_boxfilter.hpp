@@ -451,6 +451,178 @@ k_colfilter_lds_t(const float* __restrict__ srcW, const float* __restrict__ srcO
 }
 
 // ---------------------------------------------------------------------------
+// K4b''  K4b' fused with the masked division that follows the frequency-axis
+// stage of masked_gaussian_filter (flagging.py:419, 506-513, 563-566, 962): a
+// workgroup of two waves filters BOTH images of 64 lines -- wave 0 the weight
+// image, wave 1 the weight * data image -- and after every 32 steps the two
+// waves swap their 32 outputs per line through the (then idle) staging tiles,
+// so that each thread finishes 16 positions of its line:
+//     w = W / d^4, o = O / d^4, bg = (w == 0) ? NaN : o / w
+//     MODE 1: dstO = |data - bg|                 (rejection loop)
+//     MODE 2: dstO = bg, dstW = data - bg, nanflag[line] = 1 on a NaN
+// The filtered images themselves are never written: 16 B/sample of HBM traffic
+// and a kernel less per masked filter.  Arithmetic of the cascade: K4b.
+// grid (ceil(C/64), W), block 128, dynamic LDS 2 * (4 * 2r * 64 + 32 * 65) floats
+// ---------------------------------------------------------------------------
+#define CFF_BT 64
+template <int MODE>
+__global__ void __launch_bounds__(2 * CFF_BT)
+k_colfilter_lds_tf(const float* __restrict__ srcW, const float* __restrict__ srcO,
+                   float* __restrict__ dstW, float* __restrict__ dstO, const float* __restrict__ data,
+                   int n, int C, int ld, int r, float denom, size_t sws_img, size_t dws, size_t ws_data,
+                   uint8_t* __restrict__ nanflag) {
+    extern __shared__ float cf_ring[];
+    const int half = threadIdx.x >> 6;                           // 0: weight image, 1: data image
+    const int lt = threadIdx.x & 63;
+    const int c0 = blockIdx.x * CFF_BT;
+    const int c = c0 + lt;
+    const bool colok = c < C;
+    const size_t win = blockIdx.y;
+    const int R2 = 2 * r;
+    const size_t Cs = (size_t)C;
+    const float* src = (half == 0 ? srcW : srcO) + win * sws_img;
+    float* ring = cf_ring + (size_t)half * 4 * R2 * CFF_BT + lt;  // element (p, slot) at ((p*R2)+slot)*BT
+    float* tiles = cf_ring + (size_t)2 * 4 * R2 * CFF_BT;         // [2][CFT_PF][CFF_BT + 1]
+    float* tile = tiles + (size_t)half * CFT_PF * (CFF_BT + 1);
+    for (int k = 0; k < 4 * R2; k++) ring[(size_t)k * CFF_BT] = 0.0f;
+
+    // staging: element e = j * 64 + lt of a [64 lines][32 positions] patch:
+    // line = e / 32, position = e % 32  ->  lanes 0..31 read 128 contiguous bytes
+    const int s_pos = lt & 31;
+    const int s_line0 = lt >> 5;                                 // + 2 j
+    float pre[CFT_PF];
+    auto issue = [&](int t0) {
+#pragma unroll
+        for (int j = 0; j < CFT_PF; j++) {
+            int line = c0 + 2 * j + s_line0;
+            int t = t0 + s_pos;
+            pre[j] = (line < C && t < n) ? src[(size_t)line * ld + t] : 0.0f;
+        }
+    };
+    auto exchange = [&]() {
+        __syncthreads();                                         // previous tile (and hand-over) fully consumed
+#pragma unroll
+        for (int j = 0; j < CFT_PF; j++) tile[s_pos * (CFF_BT + 1) + 2 * j + s_line0] = pre[j];
+        __syncthreads();
+    };
+    // this thread finishes positions u in [16 half, 16 half + 16) of a block; their
+    // data samples are requested at the top of the block
+    const float* dcol = data + win * ws_data + (colok ? c : 0);
+    float dpre[CFT_PF / 2];
+    auto issue_data = [&](int m0) {
+#pragma unroll
+        for (int k = 0; k < CFT_PF / 2; k++) {
+            const int i = m0 + 16 * half + k - 3 - 4 * r;
+            dpre[k] = (i >= 0 && i < n && colok) ? dcol[(size_t)i * Cs] : 0.0f;
+        }
+    };
+
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0;
+    float o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;
+    int slot1 = 0, slot2 = 0, slot3 = 0, slot4 = 0;
+    float* rp1 = ring;
+    float* rp2 = ring + (size_t)(1 * R2) * CFF_BT;
+    float* rp3 = ring + (size_t)(2 * R2) * CFF_BT;
+    float* rp4 = ring + (size_t)(3 * R2) * CFF_BT;
+    float old1 = 0.0f, old2 = 0.0f, old3 = 0.0f, old4 = 0.0f;
+    auto nextslot = [&](int sl) { return (sl + 1 == R2) ? 0 : sl + 1; };
+    const int total = n + 4 * r + 3;
+
+    // one step of the cascade (K4b); returns the last stage's output
+    auto step = [&](auto fastc, const int m, const float xin) -> float {
+        constexpr bool FAST = decltype(fastc)::value;
+        const bool a4 = FAST || (m - 3 >= 0 && m - 3 < n + 4 * r);
+        const bool a3 = FAST || (m - 2 >= 0 && m - 2 < n + 4 * r);
+        const bool a2 = FAST || (m - 1 >= 0 && m - 1 < n + 4 * r);
+        const bool a1 = FAST || (m < n + R2);
+        const int ns1 = a1 ? nextslot(slot1) : slot1, ns2 = a2 ? nextslot(slot2) : slot2;
+        const int ns3 = a3 ? nextslot(slot3) : slot3, ns4 = a4 ? nextslot(slot4) : slot4;
+        const float nold1 = rp1[(size_t)ns1 * CFF_BT], nold2 = rp2[(size_t)ns2 * CFF_BT];
+        const float nold3 = rp3[(size_t)ns3 * CFF_BT], nold4 = rp4[(size_t)ns4 * CFF_BT];
+        float out = 0.0f;
+        if (a4) {
+            const int t = m - 3;
+            float in = (FAST || t >= R2) ? o3 : 0.0f;
+            rp4[(size_t)slot4 * CFF_BT] = in;
+            s4 += (double)in;
+            out = (float)s4;
+            s4 -= (double)old4;
+        }
+        if (a3) {
+            float in = o2;
+            rp3[(size_t)slot3 * CFF_BT] = in;
+            s3 += (double)in;
+            o3 = (float)s3;
+            s3 -= (double)old3;
+        }
+        if (a2) {
+            float in = (FAST || m - 1 < n + R2) ? o1 : 0.0f;
+            rp2[(size_t)slot2 * CFF_BT] = in;
+            s2 += (double)in;
+            o2 = (float)s2;
+            s2 -= (double)old2;
+        }
+        if (a1) {
+            float in = (FAST || m < n) ? xin : 0.0f;
+            rp1[(size_t)slot1 * CFF_BT] = in;
+            s1 += (double)in;
+            o1 = (float)s1;
+            s1 -= (double)old1;
+        }
+        if (a1) { old1 = nold1; slot1 = ns1; }
+        if (a2) { old2 = nold2; slot2 = ns2; }
+        if (a3) { old3 = nold3; slot3 = ns3; }
+        if (a4) { old4 = nold4; slot4 = ns4; }
+        return out;
+    };
+
+    bool line_nan = false;
+    issue(0);
+    for (int m0 = 0; m0 < total; m0 += CFT_PF) {
+        exchange();                 // tile of positions [m0, m0 + 32) in LDS
+        issue(m0 + CFT_PF);         // next tile's loads stay in flight during the arithmetic
+        issue_data(m0);
+        // every step takes its sample from tile slot (u, line) and leaves the last
+        // stage's output in the same slot (one wave per tile: LDS operations in order)
+        const bool fast = m0 >= 4 * r + 3 && m0 + CFT_PF <= n;
+        if (fast) {
+#pragma unroll
+            for (int u = 0; u < CFT_PF; u++) {
+                float* cell = tile + u * (CFF_BT + 1) + lt;
+                *cell = step(std::true_type{}, m0 + u, *cell);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < CFT_PF; u++) {
+                float* cell = tile + u * (CFF_BT + 1) + lt;
+                *cell = step(std::false_type{}, m0 + u, *cell);
+            }
+        }
+        if (m0 + CFT_PF - 1 - 3 - 4 * r < 0) continue;          // no output position in this block yet (uniform)
+        __syncthreads();
+        const float* tw = tiles;
+        const float* to = tiles + (size_t)CFT_PF * (CFF_BT + 1);
+#pragma unroll
+        for (int k = 0; k < CFT_PF / 2; k++) {
+            const int u = 16 * half + k;
+            const int i = m0 + u - 3 - 4 * r;
+            if (!(fast || (i >= 0 && i < n)) || !colok) continue;
+            const float wv = tw[u * (CFF_BT + 1) + lt] / denom;   // deferred flagging.py:419
+            const float ov = to[u * (CFF_BT + 1) + lt] / denom;
+            const float bg = (wv == 0.0f) ? NAN : ov / wv;
+            if (MODE == 1) {
+                dstO[win * dws + (size_t)i * Cs + c] = fabsf(dpre[k] - bg);
+            } else {
+                dstO[win * dws + (size_t)i * Cs + c] = bg;
+                dstW[win * dws + (size_t)i * Cs + c] = dpre[k] - bg;
+                line_nan |= isnan(bg);
+            }
+        }
+    }
+    if (MODE == 2 && line_nan && colok) nanflag[win * Cs + c] = 1;
+}
+
+// ---------------------------------------------------------------------------
 // K4c  "Lane-per-stage" form of the single-sweep box filter for medium radii
 // (the four 2r-deep delay lines of K4b no longer fit LDS at useful occupancy):
 // the four cascade stages of one line run in the four lanes of a quad, every

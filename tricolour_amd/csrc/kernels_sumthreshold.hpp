@@ -136,11 +136,8 @@ struct StFusedArgs {
     double tf[4];   // rho ** log2(w)
 };
 
-#ifndef ST_WAVES
-#define ST_WAVES 2
-#endif
 template <int W0, int W1, int W2, int W3>
-__global__ void __launch_bounds__(256, ST_WAVES)
+__global__ void __launch_bounds__(256, 2)
 k_colst_fused(const float* __restrict__ data, const double* __restrict__ med,
               uint8_t* __restrict__ out, const int64_t* __restrict__ chunk_ends,
               StFusedArgs fa, double thr_scale, int L, int C, int G, size_t ws_data,
@@ -218,7 +215,6 @@ k_colst_fused(const float* __restrict__ data, const double* __restrict__ med,
 #pragma unroll
     for (int u = 0; u < UN; u++) cur[u] = (u < Lp) ? x[(size_t)u * Cs] : 0.0f;
 
-    unsigned exp_acc = 0;   // ST_EXP_NOSTORE experiment only
     auto block = [&](auto fastc, const int base) {
         constexpr bool fast = decltype(fastc)::value;
 #pragma unroll
@@ -231,9 +227,6 @@ k_colst_fused(const float* __restrict__ data, const double* __restrict__ med,
             // at the previous tick
 #pragma unroll
             for (int j = 3; j >= 0; j--) {
-#ifdef ST_EXP_STAGES
-                if (j >= ST_EXP_STAGES) continue;
-#endif
                 const int w = W[j];
                 const int i = n - D[j];        // ingest position
                 const int e = i + 1 - w;       // emit position
@@ -277,11 +270,7 @@ k_colst_fused(const float* __restrict__ data, const double* __restrict__ med,
             }
             const int ef = n - DOUT;
             const int fs = (PH - DOUT) & (UN - 1);
-#ifdef ST_EXP_NOSTORE
-            exp_acc |= accP[fs] | accN[fs];
-#else
             if (fast || (ef >= o0 && ef < o1)) o[(size_t)ef * Cs] = (uint8_t)(accP[fs] | accN[fs]);
-#endif
             accP[fs] = 0;
             accN[fs] = 0;
         }
@@ -292,11 +281,6 @@ k_colst_fused(const float* __restrict__ data, const double* __restrict__ med,
         if (fast) block(std::true_type{}, base);
         else block(std::false_type{}, base);
     }
-#ifdef ST_EXP_NOSTORE
-    o[0] = (uint8_t)exp_acc;
-#else
-    (void)exp_acc;
-#endif
 }
 
 

@@ -640,6 +640,30 @@ int launch_colfilter_t(const Run& r, const float* srcW, const float* srcO, float
     return TRI_OK;
 }
 
+// The same stage fused with the masked division that follows it (k_colfilter_lds_tf):
+// MODE 1 leaves |data - background| in dstO, MODE 2 the background in dstO, the signed
+// residual in dstW and the per-line NaN markers.  TRI_FILTER_NO_FUSED_DIV=1 keeps the
+// separate kernels (A/B runs).
+bool colfilter_tf_usable(int rad) {
+    static const bool off = [] { const char* e = getenv("TRI_FILTER_NO_FUSED_DIV"); return e && e[0] == '1'; }();
+    return !off && colfilter_t_usable(rad);
+}
+
+template <int MODE>
+int launch_colfilter_tf(const Run& r, const float* srcW, const float* srcO, float* dstW, float* dstO, const float* data,
+                        int n, int C, int ld, int rad, size_t sws_img, size_t dws, size_t ws_data, int64_t W, uint8_t* nanflag) {
+    float denom = box_denominator(rad);
+    size_t lds = (size_t)2 * ((size_t)4 * 2 * rad * CFF_BT + (size_t)CFT_PF * (CFF_BT + 1)) * sizeof(float);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds_tf<MODE>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    HIPCHK(attr);
+    dim3 grid((unsigned)cdiv(C, CFF_BT), (unsigned)W);
+    hipLaunchKernelGGL(k_colfilter_lds_tf<MODE>, grid, dim3(2 * CFF_BT), lds, r.st, srcW, srcO, dstW, dstO, data, n, C, ld, rad,
+                       denom, sws_img, dws, ws_data, nanflag);
+    LAUNCHCHK();
+    return TRI_OK;
+}
+
 // Lane-per-stage variant of the same (radii 17..LANE4_R_MAX): k_colfilter_lane4<3, *>.
 bool colfilter_t4_usable(int rad) {
     static const bool off = [] { const char* e = getenv("TRI_FILTER_NO_TIN"); return e && e[0] == '1'; }();
@@ -799,7 +823,17 @@ int background2d(const Run& r) {
         // --- to FT layout: rows [4 r1, 4 r1 + Fa) of the padded buffers for the
         //     in-place multi-pass filter, rows [0, Fa) for the single-sweep one ---
         size_t off = colfilter_lds_block(r1, T) > 0 ? 0 : (size_t)4 * r1 * T;
-        if (tin && !direct_ft) {
+        // frequency stage + masked division in one kernel when the four-ring stage applies
+        const bool fused_div = tin && !tin4 && !direct_ft && colfilter_tf_usable(r1);
+        if (fused_div) {
+            if (final_pass) {
+                HIPCHK(hipMemsetAsync(ws.rowcnt, 0, (size_t)W * T, r.st));
+                rc = launch_colfilter_tf<2>(r, ws.Aw, ws.Ao, ws.Bw, ws.Bo, ws.dataFT, Fa, T, Fa, r1, wsA, wsB, N, W, reinterpret_cast<uint8_t*>(ws.rowcnt));
+            } else {
+                rc = launch_colfilter_tf<1>(r, ws.Aw, ws.Ao, ws.Bw, ws.Bo, ws.dataFT, Fa, T, Fa, r1, wsA, wsB, N, W, nullptr);
+            }
+            if (rc) return rc;
+        } else if (tin && !direct_ft) {
             if (tin4) rc = launch_colfilter_t4(r, ws.Aw, ws.Ao, ws.Bw, ws.Bo, Fa, T, Fa, r1, wsA, wsB, W, &den_f);
             else rc = launch_colfilter_t(r, ws.Aw, ws.Ao, ws.Bw, ws.Bo, Fa, T, Fa, r1, wsA, wsB, W, &den_f);
             if (rc) return rc;
@@ -817,12 +851,16 @@ int background2d(const Run& r) {
         if (final_pass) {
             // ws.rowcnt (W * T ints, idle until the end of the iteration) doubles as the
             // per-line "background holds a NaN" marker
-            HIPCHK(hipMemsetAsync(ws.rowcnt, 0, (size_t)W * T, r.st));
-            rc = launch_masked_div<2>(r, ws.Bw, ws.Bo, ws.dataFT, N, wsB, N, W, den_f, reinterpret_cast<uint8_t*>(ws.rowcnt), T);
-            if (rc) return rc;
+            if (!fused_div) {
+                HIPCHK(hipMemsetAsync(ws.rowcnt, 0, (size_t)W * T, r.st));
+                rc = launch_masked_div<2>(r, ws.Bw, ws.Bo, ws.dataFT, N, wsB, N, W, den_f, reinterpret_cast<uint8_t*>(ws.rowcnt), T);
+                if (rc) return rc;
+            }
         } else {
-            rc = launch_masked_div<1>(r, ws.Bw, ws.Bo, ws.dataFT, N, wsB, N, W, den_f);
-            if (rc) return rc;
+            if (!fused_div) {
+                rc = launch_masked_div<1>(r, ws.Bw, ws.Bo, ws.dataFT, N, wsB, N, W, den_f);
+                if (rc) return rc;
+            }
             // block medians over (all times) x (chunk channels): contiguous in FT
             rc = launch_median(r, ws.Bo, ws.bgfFT, ws.med, wsB, N, 0, 1, ws.segB_start, ws.segB_len, 1, G, W, pl.maxchunk * pl.T,
                                T % 4 == 0 && wsB % 4 == 0 && N % 4 == 0);
