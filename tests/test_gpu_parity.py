@@ -261,6 +261,13 @@ EDGE_CASES = [
     ((1, 1, 64, 128), dict(num_major_iterations=1, outlier_nsigma=0.0)),
     ((3, 1, 16, 32), dict(num_major_iterations=0)),
     ((1, 1, 128, 64), dict(num_major_iterations=1, spike_width_time=45.0, background_iterations=2)),  # radii up to 77
+    # awkward extents for the single-sweep filters: lines / positions that are no multiple of the
+    # 16-, 64- or 128-line workgroups and of the 32-step blocks
+    ((1, 1, 100, 150), dict(num_major_iterations=2)),                                   # K4b time, fused K4b'' frequency
+    ((2, 1, 68, 97), dict(num_major_iterations=1, background_iterations=2)),            # odd channel count
+    ((1, 1, 76, 200), dict(num_major_iterations=1, spike_width_time=30.0, spike_width_freq=25.0)),   # K4c both axes (r = 25, 21)
+    ((1, 1, 256, 96), dict(num_major_iterations=1, spike_width_time=130.0, spike_width_freq=20.0)),  # r = 112 > n / 4
+    ((1, 2, 52, 120), dict(num_major_iterations=2, background_iterations=3)),           # radii 32 / 25 ... 10 / 8
 ]
 
 
