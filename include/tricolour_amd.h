@@ -42,7 +42,8 @@ enum tri_status {
 
 enum tri_vis_dtype {
     TRI_VIS_C64 = 0,     /* interleaved (re, im) float32 -- MS DATA columns     */
-    TRI_VIS_F32 = 1      /* real float32 amplitudes (flagging.py:830-832)       */
+    TRI_VIS_F32 = 1,     /* real float32 amplitudes (flagging.py:830-832)       */
+    TRI_VIS_C128 = 2     /* interleaved float64: tri_stokes_intensity only       */
 };
 
 /*
@@ -154,6 +155,23 @@ int tri_unpack_data(const uint8_t *flag_windows,
                     int64_t rows, int64_t nchan, int64_t ncorr,
                     int64_t nbl, int64_t ntime,
                     uint8_t *out_flags, int any_corr, void *stream);
+
+/*
+ * Replaces tricolour.stokes.polarised_intensity (stokes.py:157-209, mode 0)
+ * and unpolarised_intensity (stokes.py:79-153, mode 1) on (row, chan, corr)
+ * visibilities, n = row * chan samples:
+ *   value_k = a_k * (s1_k * vis[c1_k] + s2_k * vis[c2_k])     in complex128
+ *   mode 0: out = sqrt(sum_pol |value|^2)
+ *   mode 1: out = sum_unpol |value| - sqrt(sum_pol |value|^2)
+ * written as one correlation of the visibility dtype (imaginary part 0).
+ * Term tables are HOST arrays: idx = (c1, c2, s1, s2) per term, alpha =
+ * (re, im) per term (the (c1, c2, a, s1, s2) tuples of stokes_corr_map).
+ * vis_dtype: TRI_VIS_C64 or TRI_VIS_C128.
+ */
+int tri_stokes_intensity(const void *vis, int vis_dtype, int64_t n, int64_t ncorr,
+                         const int32_t *pol_idx, const double *pol_alpha, int64_t n_pol,
+                         const int32_t *unpol_idx, const double *unpol_alpha, int64_t n_unpol,
+                         int mode, void *out, void *stream);
 
 /*
  * Flag counts behind tricolour.window_statistics._window_stats

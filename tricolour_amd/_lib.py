@@ -30,7 +30,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17",
                "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 
 TRI_OK, TRI_EINVAL, TRI_EUNSUPPORTED, TRI_EWORKSPACE, TRI_EHIP = range(5)
-TRI_VIS_C64, TRI_VIS_F32 = 0, 1
+TRI_VIS_C64, TRI_VIS_F32, TRI_VIS_C128 = 0, 1, 2
 TRI_MAX_WINDOWS = 16
 
 
@@ -110,6 +110,10 @@ _SIGNATURES = {
     "tri_flag_nans_and_zeros": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "tri_apply_baseline_channel_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                                   C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
+    "tri_stokes_intensity": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64,
+                                       C.c_void_p, C.c_void_p, C.c_int64,
+                                       C.c_void_p, C.c_void_p, C.c_int64,
+                                       C.c_int, C.c_void_p, C.c_void_p]),
     "tri_window_counts": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "tri_uvcontsub_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),

@@ -862,3 +862,56 @@ k_window_counts(const uint8_t* __restrict__ flags, unsigned long long* __restric
         if (tot) atomicAdd(&per_bl[bl], tot);
     }
 }
+
+// ---------------------------------------------------------------------------
+// Polarised / unpolarised intensity of (row, chan, corr) visibilities
+// (stokes.py:157-209 and :79-153) with numba's typing: every term
+//   value = a * (s1 * vis[c1] + s2 * vis[c2])
+// is formed in complex128 (int64 * complex64 promotes), |value| is the double
+// hypot, pol = sum |value|^2 and unpol = sum |value| accumulate in float64, and
+//   mode 0: out = sqrt(pol)            mode 1: out = unpol - sqrt(pol)
+// is cast to the visibility dtype (imaginary part 0).  One thread per
+// (row, chan); the correlations of a sample are contiguous.
+// ---------------------------------------------------------------------------
+#define TRI_MAX_STOKES_TERMS 4
+struct StokesTerm {
+    int c1, c2, s1, s2;
+    double ar, ai;
+};
+struct StokesTerms {
+    int n_pol, n_unpol;
+    StokesTerm pol[TRI_MAX_STOKES_TERMS];
+    StokesTerm unpol[TRI_MAX_STOKES_TERMS];
+};
+
+template <typename T>   // float (complex64) or double (complex128)
+__global__ void k_stokes_intensity(const T* __restrict__ vis, T* __restrict__ out, size_t n, int ncorr,
+                                   StokesTerms terms, int mode) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const T* v = vis + i * (size_t)ncorr * 2;
+    auto magnitude = [&](const StokesTerm& t) {
+        // s * (re + i im) with s = (double)s + 0i, then the sum, then a * (...): numba's complex products
+        const double x1r = (double)v[2 * t.c1], x1i = (double)v[2 * t.c1 + 1];
+        const double x2r = (double)v[2 * t.c2], x2i = (double)v[2 * t.c2 + 1];
+        const double s1 = (double)t.s1, s2 = (double)t.s2;
+        const double p1r = s1 * x1r - 0.0 * x1i, p1i = s1 * x1i + 0.0 * x1r;
+        const double p2r = s2 * x2r - 0.0 * x2i, p2i = s2 * x2i + 0.0 * x2r;
+        const double sr = p1r + p2r, si = p1i + p2i;
+        const double vr = t.ar * sr - t.ai * si, vi = t.ar * si + t.ai * sr;
+        return hypot(vr, vi);
+    };
+    double pol = 0.0;
+    for (int k = 0; k < terms.n_pol; k++) {
+        const double m = magnitude(terms.pol[k]);
+        pol += m * m;
+    }
+    double res = sqrt(pol);
+    if (mode == 1) {
+        double unpol = 0.0;
+        for (int k = 0; k < terms.n_unpol; k++) unpol += magnitude(terms.unpol[k]);
+        res = unpol - res;
+    }
+    out[2 * i] = (T)res;
+    out[2 * i + 1] = (T)0;
+}

@@ -1293,6 +1293,43 @@ extern "C" int tri_flag_nans_and_zeros(const void* vis, int vis_dtype, const uin
     return TRI_OK;
 }
 
+extern "C" int tri_stokes_intensity(const void* vis, int vis_dtype, int64_t n, int64_t ncorr,
+                                    const int32_t* pol_idx, const double* pol_alpha, int64_t n_pol,
+                                    const int32_t* unpol_idx, const double* unpol_alpha, int64_t n_unpol,
+                                    int mode, void* out, void* stream) {
+    if (n < 0 || ncorr <= 0 || n_pol < 0 || n_unpol < 0) return set_err(TRI_EINVAL, "bad shape");
+    if (mode != 0 && mode != 1) return set_err(TRI_EINVAL, "mode must be 0 (polarised) or 1 (unpolarised)");
+    if (vis_dtype != TRI_VIS_C64 && vis_dtype != TRI_VIS_C128) return set_err(TRI_EUNSUPPORTED, "visibilities must be complex64 or complex128");
+    if (n_pol > TRI_MAX_STOKES_TERMS || n_unpol > TRI_MAX_STOKES_TERMS) return set_err(TRI_EUNSUPPORTED, "at most 4 stokes terms per kind");
+    if ((n_pol > 0 && (!pol_idx || !pol_alpha)) || (n_unpol > 0 && (!unpol_idx || !unpol_alpha))) return set_err(TRI_EINVAL, "NULL pointer argument");
+    StokesTerms terms;
+    terms.n_pol = (int)n_pol;
+    terms.n_unpol = (int)n_unpol;
+    auto fill = [&](StokesTerm* dst, const int32_t* idx, const double* alpha, int64_t cnt) -> bool {
+        for (int64_t k = 0; k < cnt; k++) {
+            dst[k].c1 = idx[4 * k];
+            dst[k].c2 = idx[4 * k + 1];
+            dst[k].s1 = idx[4 * k + 2];
+            dst[k].s2 = idx[4 * k + 3];
+            dst[k].ar = alpha[2 * k];
+            dst[k].ai = alpha[2 * k + 1];
+            if (dst[k].c1 < 0 || dst[k].c1 >= ncorr || dst[k].c2 < 0 || dst[k].c2 >= ncorr) return false;
+        }
+        return true;
+    };
+    if (!fill(terms.pol, pol_idx, pol_alpha, n_pol) || !fill(terms.unpol, unpol_idx, unpol_alpha, n_unpol))
+        return set_err(TRI_EINVAL, "correlation index out of range");
+    if (n == 0) return TRI_OK;
+    if (!vis || !out) return set_err(TRI_EINVAL, "NULL pointer argument");
+    dim3 grid((unsigned)cdiv(n, 256));
+    if (vis_dtype == TRI_VIS_C64)
+        hipLaunchKernelGGL(k_stokes_intensity<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)vis, (float*)out, (size_t)n, (int)ncorr, terms, mode);
+    else
+        hipLaunchKernelGGL(k_stokes_intensity<double>, grid, dim3(256), 0, (hipStream_t)stream, (const double*)vis, (double*)out, (size_t)n, (int)ncorr, terms, mode);
+    LAUNCHCHK();
+    return TRI_OK;
+}
+
 extern "C" int tri_window_counts(const uint8_t* flags, int64_t nbl, int64_t ncorr, int64_t ntime,
                                  int64_t nchan, uint64_t* per_bl, uint64_t* per_chan, void* stream) {
     if (!per_bl || !per_chan) return set_err(TRI_EINVAL, "NULL pointer argument");

@@ -1,5 +1,6 @@
-"""Graph-level drop-ins for ``tricolour.dask_wrappers.sum_threshold_flagger``
-and ``uvcontsub_flagger`` (reference ``tricolour/dask_wrappers.py:23-66``).
+"""Graph-level drop-ins for ``tricolour.dask_wrappers.sum_threshold_flagger``,
+``uvcontsub_flagger`` (reference ``tricolour/dask_wrappers.py:23-66``) and the
+Stokes intensity transforms (``:117-147``).
 
 Same call signatures and the same result as the reference wrappers: a dask
 array with the chunking of ``vis`` and the dtype of ``flag`` whose graph holds
@@ -12,6 +13,8 @@ dask is imported lazily: it is only needed when a graph is built.
 from tricolour_amd.flagging import sum_threshold_flagger as amd_sum_threshold_flagger
 from tricolour_amd.flagging import uvcontsub_flagger as amd_uvcontsub_flagger
 from tricolour_amd.packing import _WINDOW_SCHEMA
+from tricolour_amd.stokes import polarised_intensity as amd_polarised_intensity
+from tricolour_amd.stokes import unpolarised_intensity as amd_unpolarised_intensity
 
 
 def _window_blockwise(per_block, layer_name, vis, flag, kwargs):
@@ -50,3 +53,23 @@ def uvcontsub_flagger(vis, flag, **kwargs):
     token = da.core.tokenize(vis, flag, **kwargs)
     return _window_blockwise(amd_uvcontsub_flagger, 'uvcontsub-flagger-' + token,
                              vis, flag, kwargs)
+
+
+_ROW_SCHEMA = ("row", "chan", "corr")
+
+
+def _single_corr_blockwise(per_block, vis, **terms):
+    """(row, chan, corr) -> (row, chan, 1), block by block."""
+    import dask.array as da
+    return da.blockwise(lambda block, **kw: per_block(block, **kw), _ROW_SCHEMA, vis, _ROW_SCHEMA,
+                        adjust_chunks={"corr": 1}, dtype=vis.dtype, **terms)
+
+
+def polarised_intensity(vis, stokes_pol):
+    """Dask wrapper for :func:`tricolour_amd.stokes.polarised_intensity`."""
+    return _single_corr_blockwise(amd_polarised_intensity, vis, stokes_pol=stokes_pol)
+
+
+def unpolarised_intensity(vis, stokes_unpol, stokes_pol):
+    """Dask wrapper for :func:`tricolour_amd.stokes.unpolarised_intensity`."""
+    return _single_corr_blockwise(amd_unpolarised_intensity, vis, stokes_unpol=stokes_unpol, stokes_pol=stokes_pol)
