@@ -2,7 +2,8 @@
 """Sums rocprofv3 --pmc counters per kernel: pmc_report.py <dir> [kernel-substring]"""
 import collections, csv, glob, sys
 d, pat = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "")
-f = sorted(glob.glob(d + "/*/*_counter_collection.csv"))[-1]
+import os
+f = max(glob.glob(d + "/*/*_counter_collection.csv"), key=os.path.getmtime)
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(set)
 for r in csv.DictReader(open(f)):

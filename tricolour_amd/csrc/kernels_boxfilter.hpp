@@ -158,7 +158,7 @@ k_colfilter_lds(const float* __restrict__ srcW, const float* __restrict__ srcO,
     // so the frequency-axis stage can consume it without a transpose pass.
     float* dst = (img == 0 ? dstW : dstO) + win * dws + (TOUT ? (size_t)c * n : (size_t)c);
     float tacc0 = 0.0f, tacc1 = 0.0f, tacc2 = 0.0f;
-    float* ring = cf_ring + threadIdx.x;            // element (p, slot) at ((p*R2)+slot)*BT
+    float* ring = cf_ring + threadIdx.x;            // element (slot, p) at ((slot*4)+p)*BT
     for (int k = 0; k < 4 * R2; k++) ring[(size_t)k * BT] = 0.0f;
 
     auto load = [&](int t) -> float {
@@ -187,7 +187,6 @@ k_colfilter_lds(const float* __restrict__ srcW, const float* __restrict__ srcO,
     using A = typename std::conditional<decltype(intw_tag)::value, int, double>::type;
     A s1 = 0, s2 = 0, s3 = 0, s4 = 0;
     V o1 = 0, o2 = 0, o3 = 0;                    // stage outputs of the previous step
-    int slot1 = 0, slot2 = 0, slot3 = 0, slot4 = 0;
     const int total = n + 4 * r + 3;
     // Deep prefetch: with the LDS rings capping occupancy at 2 waves / SIMD,
     // bytes in flight (Little's law against ~2 us of HBM latency) come from
@@ -224,78 +223,61 @@ k_colfilter_lds(const float* __restrict__ srcW, const float* __restrict__ srcO,
     // One cascade step.  FAST = every stage is inside its steady range
     // (4r + 3 <= m, m < n): no bounds tests, so the four float64 chains of a
     // step are straight-line code the scheduler can interleave.
-    // Ring reads are issued one step ahead (R2 >= 2, so the slot read for step
-    // m + 1 differs from the slot written at step m): their LDS latency hides
-    // behind the arithmetic of the current step instead of stalling each stage.
-    V* rp1 = reinterpret_cast<V*>(ring);
-    V* rp2 = reinterpret_cast<V*>(ring) + (size_t)(1 * R2) * BT;
-    V* rp3 = reinterpret_cast<V*>(ring) + (size_t)(2 * R2) * BT;
-    V* rp4 = reinterpret_cast<V*>(ring) + (size_t)(3 * R2) * BT;
+    // The delay lines are indexed by the step counter: every stage writes slot
+    // m mod 2r at EVERY step (inputs outside a stage's range are zero and leave
+    // its sum unchanged), so the slot being written holds exactly the sample
+    // that leaves the window, all four stages share one wave-uniform slot
+    // index, and only the stores are range-checked.  The trailing samples are
+    // read one step ahead (2r >= 2, so that cell is not the one written now):
+    // their LDS latency hides behind the arithmetic of the current step.
+    V* cells = reinterpret_cast<V*>(ring);      // element (slot, p) at ((slot*4)+p)*BT
+    const size_t BT4 = (size_t)4 * BT;
+    int slot = 0;
     V old1 = 0, old2 = 0, old3 = 0, old4 = 0;   // rings start zeroed (all-zero bits in either type)
-    auto nextslot = [&](int sl) { return (sl + 1 == R2) ? 0 : sl + 1; };
 
     auto step = [&](auto fastc, const int m, const float xin) {
         constexpr bool FAST = decltype(fastc)::value;
-        const bool a4 = FAST || (m - 3 >= 0 && m - 3 < n + 4 * r);
-        const bool a3 = FAST || (m - 2 >= 0 && m - 2 < n + 4 * r);
-        const bool a2 = FAST || (m - 1 >= 0 && m - 1 < n + 4 * r);
-        const bool a1 = FAST || (m < n + R2);
-        const int ns1 = a1 ? nextslot(slot1) : slot1, ns2 = a2 ? nextslot(slot2) : slot2;
-        const int ns3 = a3 ? nextslot(slot3) : slot3, ns4 = a4 ? nextslot(slot4) : slot4;
-        // prefetch next step's trailing samples
-        const V nold1 = rp1[(size_t)ns1 * BT], nold2 = rp2[(size_t)ns2 * BT];
-        const V nold3 = rp3[(size_t)ns3 * BT], nold4 = rp4[(size_t)ns4 * BT];
+        V* cell = cells + (size_t)slot * BT4;
+        slot = (slot + 1 == R2) ? 0 : slot + 1;
+        const V* ncell = cells + (size_t)slot * BT4;
+        const V nold1 = ncell[0], nold2 = ncell[BT], nold3 = ncell[2 * (size_t)BT], nold4 = ncell[3 * (size_t)BT];
         // stage 4 (time t4 = m - 3): input out_3[t4], present for 2r <= t4 < n + 4r
-        if (a4) {
-            const int t = m - 3;
-            V in = (FAST || t >= R2) ? o3 : (V)0;
-            rp4[(size_t)slot4 * BT] = in;
-            s4 += (A)in;
-            float out = (float)s4;
-            s4 -= (A)old4;
-            int i = t - 4 * r;
-            if (FAST || i >= 0) {
-                float y = DIV ? out / denom : out;
-                if (TOUT) {
-                    const int ph = i & 3;
-                    if (ph == 0) tacc0 = y;
-                    else if (ph == 1) tacc1 = y;
-                    else if (ph == 2) tacc2 = y;
-                    else *reinterpret_cast<float4*>(dst + (i - 3)) = make_float4(tacc0, tacc1, tacc2, y);
-                } else {
-                    dst[(size_t)i * Cs] = y;
-                }
+        // stage 3 (t3 = m - 2): input out_2[t3];  stage 2 (t2 = m - 1): input out_1[t2]
+        // for t2 < n + 2r;  stage 1 (t1 = m): input data[t1] (zero beyond the line end)
+        const V in4 = (FAST || m - 3 >= R2) ? o3 : (V)0;
+        const V in3 = o2;
+        const V in2 = (FAST || m - 1 < n + R2) ? o1 : (V)0;
+        const V in1 = (FAST || m < n) ? (V)xin : (V)0;
+        cell[3 * (size_t)BT] = in4;
+        cell[2 * (size_t)BT] = in3;
+        cell[BT] = in2;
+        cell[0] = in1;
+        s4 += (A)in4;
+        const float out = (float)s4;
+        s4 -= (A)old4;
+        s3 += (A)in3;
+        o3 = (V)s3;
+        s3 -= (A)old3;
+        s2 += (A)in2;
+        o2 = (V)s2;
+        s2 -= (A)old2;
+        s1 += (A)in1;
+        o1 = (V)s1;
+        s1 -= (A)old1;
+        old1 = nold1; old2 = nold2; old3 = nold3; old4 = nold4;
+        const int i = m - 3 - 4 * r;
+        if (FAST || (i >= 0 && i < n)) {
+            float y = DIV ? out / denom : out;
+            if (TOUT) {
+                const int ph = i & 3;
+                if (ph == 0) tacc0 = y;
+                else if (ph == 1) tacc1 = y;
+                else if (ph == 2) tacc2 = y;
+                else *reinterpret_cast<float4*>(dst + (i - 3)) = make_float4(tacc0, tacc1, tacc2, y);
+            } else {
+                dst[(size_t)i * Cs] = y;
             }
         }
-        // stage 3 (t3 = m - 2): input out_2[t3], t3 in [0, n + 4r)
-        if (a3) {
-            V in = o2;
-            rp3[(size_t)slot3 * BT] = in;
-            s3 += (A)in;
-            o3 = (V)s3;
-            s3 -= (A)old3;
-        }
-        // stage 2 (t2 = m - 1): input out_1[t2] for t2 < n + 2r, then drains to n + 4r
-        if (a2) {
-            V in = (FAST || m - 1 < n + R2) ? o1 : (V)0;
-            rp2[(size_t)slot2 * BT] = in;
-            s2 += (A)in;
-            o2 = (V)s2;
-            s2 -= (A)old2;
-        }
-        // stage 1 (t1 = m): input data[t1] for t1 < n, drains to n + 2r
-        if (a1) {
-            V in = (FAST || m < n) ? (V)xin : (V)0;
-            rp1[(size_t)slot1 * BT] = in;
-            s1 += (A)in;
-            o1 = (V)s1;
-            s1 -= (A)old1;
-        }
-        // a stage that did not run keeps its pending trailing sample
-        if (a1) { old1 = nold1; slot1 = ns1; }
-        if (a2) { old2 = nold2; slot2 = ns2; }
-        if (a3) { old3 = nold3; slot3 = ns3; }
-        if (a4) { old4 = nold4; slot4 = ns4; }
     };
 
     for (int m0 = 0; m0 < total; m0 += PF) {
@@ -481,7 +463,7 @@ k_colfilter_lds_tf(const float* __restrict__ srcW, const float* __restrict__ src
     const int R2 = 2 * r;
     const size_t Cs = (size_t)C;
     const float* src = (half == 0 ? srcW : srcO) + win * sws_img;
-    float* ring = cf_ring + (size_t)half * 4 * R2 * CFF_BT + lt;  // element (p, slot) at ((p*R2)+slot)*BT
+    float* ring = cf_ring + (size_t)half * 4 * R2 * CFF_BT + lt;  // element (slot, p) at ((slot*4)+p)*BT
     float* tiles = cf_ring + (size_t)2 * 4 * R2 * CFF_BT;         // [2][CFT_PF][CFF_BT + 1]
     float* tile = tiles + (size_t)half * CFT_PF * (CFF_BT + 1);
     for (int k = 0; k < 4 * R2; k++) ring[(size_t)k * CFF_BT] = 0.0f;
@@ -517,62 +499,46 @@ k_colfilter_lds_tf(const float* __restrict__ srcW, const float* __restrict__ src
         }
     };
 
+    // Delay lines indexed by the step counter: every stage writes slot m mod 2r at
+    // every step (inputs outside a stage's range are zero and leave its float64 sum
+    // unchanged), so the slot being written holds exactly the sample that leaves the
+    // window, all four stages share one wave-uniform slot index, and the four cells of
+    // a slot sit at immediate offsets of one LDS address ((slot, stage) interleaved).
     double s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0;
     float o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;
-    int slot1 = 0, slot2 = 0, slot3 = 0, slot4 = 0;
-    float* rp1 = ring;
-    float* rp2 = ring + (size_t)(1 * R2) * CFF_BT;
-    float* rp3 = ring + (size_t)(2 * R2) * CFF_BT;
-    float* rp4 = ring + (size_t)(3 * R2) * CFF_BT;
-    float old1 = 0.0f, old2 = 0.0f, old3 = 0.0f, old4 = 0.0f;
-    auto nextslot = [&](int sl) { return (sl + 1 == R2) ? 0 : sl + 1; };
+    int slot = 0;
+    float old1 = 0.0f, old2 = 0.0f, old3 = 0.0f, old4 = 0.0f;    // trailing samples of the coming step
     const int total = n + 4 * r + 3;
 
-    // one step of the cascade (K4b); returns the last stage's output
+    // one step of the cascade (K4b arithmetic); returns the last stage's output
     auto step = [&](auto fastc, const int m, const float xin) -> float {
         constexpr bool FAST = decltype(fastc)::value;
-        const bool a4 = FAST || (m - 3 >= 0 && m - 3 < n + 4 * r);
-        const bool a3 = FAST || (m - 2 >= 0 && m - 2 < n + 4 * r);
-        const bool a2 = FAST || (m - 1 >= 0 && m - 1 < n + 4 * r);
-        const bool a1 = FAST || (m < n + R2);
-        const int ns1 = a1 ? nextslot(slot1) : slot1, ns2 = a2 ? nextslot(slot2) : slot2;
-        const int ns3 = a3 ? nextslot(slot3) : slot3, ns4 = a4 ? nextslot(slot4) : slot4;
-        const float nold1 = rp1[(size_t)ns1 * CFF_BT], nold2 = rp2[(size_t)ns2 * CFF_BT];
-        const float nold3 = rp3[(size_t)ns3 * CFF_BT], nold4 = rp4[(size_t)ns4 * CFF_BT];
-        float out = 0.0f;
-        if (a4) {
-            const int t = m - 3;
-            float in = (FAST || t >= R2) ? o3 : 0.0f;
-            rp4[(size_t)slot4 * CFF_BT] = in;
-            s4 += (double)in;
-            out = (float)s4;
-            s4 -= (double)old4;
-        }
-        if (a3) {
-            float in = o2;
-            rp3[(size_t)slot3 * CFF_BT] = in;
-            s3 += (double)in;
-            o3 = (float)s3;
-            s3 -= (double)old3;
-        }
-        if (a2) {
-            float in = (FAST || m - 1 < n + R2) ? o1 : 0.0f;
-            rp2[(size_t)slot2 * CFF_BT] = in;
-            s2 += (double)in;
-            o2 = (float)s2;
-            s2 -= (double)old2;
-        }
-        if (a1) {
-            float in = (FAST || m < n) ? xin : 0.0f;
-            rp1[(size_t)slot1 * CFF_BT] = in;
-            s1 += (double)in;
-            o1 = (float)s1;
-            s1 -= (double)old1;
-        }
-        if (a1) { old1 = nold1; slot1 = ns1; }
-        if (a2) { old2 = nold2; slot2 = ns2; }
-        if (a3) { old3 = nold3; slot3 = ns3; }
-        if (a4) { old4 = nold4; slot4 = ns4; }
+        float* cell = ring + (size_t)slot * 4 * CFF_BT;
+        slot = (slot + 1 == R2) ? 0 : slot + 1;
+        const float* ncell = ring + (size_t)slot * 4 * CFF_BT;
+        // the next step's trailing samples (2r >= 2: not the cell written below)
+        const float nold1 = ncell[0], nold2 = ncell[CFF_BT], nold3 = ncell[2 * CFF_BT], nold4 = ncell[3 * CFF_BT];
+        const float in4 = (FAST || m - 3 >= R2) ? o3 : 0.0f;
+        const float in3 = o2;
+        const float in2 = (FAST || m - 1 < n + R2) ? o1 : 0.0f;
+        const float in1 = xin;                                   // zero beyond the line end by construction
+        cell[3 * CFF_BT] = in4;
+        cell[2 * CFF_BT] = in3;
+        cell[CFF_BT] = in2;
+        cell[0] = in1;
+        s4 += (double)in4;
+        const float out = (float)s4;
+        s4 -= (double)old4;
+        s3 += (double)in3;
+        o3 = (float)s3;
+        s3 -= (double)old3;
+        s2 += (double)in2;
+        o2 = (float)s2;
+        s2 -= (double)old2;
+        s1 += (double)in1;
+        o1 = (float)s1;
+        s1 -= (double)old1;
+        old1 = nold1; old2 = nold2; old3 = nold3; old4 = nold4;
         return out;
     };
 
