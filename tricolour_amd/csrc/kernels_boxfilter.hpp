@@ -551,17 +551,22 @@ k_colfilter_lds_tf(const float* __restrict__ srcW, const float* __restrict__ src
         // every step takes its sample from tile slot (u, line) and leaves the last
         // stage's output in the same slot (one wave per tile: LDS operations in order)
         const bool fast = m0 >= 4 * r + 3 && m0 + CFT_PF <= n;
+        // (the sample of step u + 1 is read before step u's LDS writes, so its latency hides
+        //  behind a whole step of arithmetic)
+        float xin = tile[lt];
         if (fast) {
 #pragma unroll
             for (int u = 0; u < CFT_PF; u++) {
-                float* cell = tile + u * (CFF_BT + 1) + lt;
-                *cell = step(std::true_type{}, m0 + u, *cell);
+                const float xnext = (u + 1 < CFT_PF) ? tile[(u + 1) * (CFF_BT + 1) + lt] : 0.0f;
+                tile[u * (CFF_BT + 1) + lt] = step(std::true_type{}, m0 + u, xin);
+                xin = xnext;
             }
         } else {
 #pragma unroll
             for (int u = 0; u < CFT_PF; u++) {
-                float* cell = tile + u * (CFF_BT + 1) + lt;
-                *cell = step(std::false_type{}, m0 + u, *cell);
+                const float xnext = (u + 1 < CFT_PF) ? tile[(u + 1) * (CFF_BT + 1) + lt] : 0.0f;
+                tile[u * (CFF_BT + 1) + lt] = step(std::false_type{}, m0 + u, xin);
+                xin = xnext;
             }
         }
         if (m0 + CFT_PF - 1 - 3 - 4 * r < 0) continue;          // no output position in this block yet (uniform)
