@@ -247,7 +247,7 @@ int tri_version(void);
  *   out  (n_win, n_line, n_col) uint8
  * `variant`: 0 = best available for these windows, 1 = generic (dynamic
  * windows, global rings), 2 = register cascade (windows 1,2,4,8 only),
- * 3 = lane-mask cascade (windows 1,2,4,8, window below 2^32 bytes; what 0
+ * 3 = lane-mask cascade (windows 1,2,4,8, window below 2^31 bytes; what 0
  * selects for those).
  */
 int tri_bench_sumthreshold(const float *data, const double *mad, uint8_t *out,

@@ -308,7 +308,7 @@ k_colst_fused(const float* __restrict__ data, const double* __restrict__ med,
 // Interior blocks of 16 ticks are branch-free and form their own loop; the
 // samples of the NEXT block are requested in one burst at the top of a block,
 // so every load has 16..31 ticks to land.
-// grid (ceil(C/BLK), G, W), block BLK;  needs L * C * 4 < 2^32
+// grid (ceil(C/BLK), G, W), block BLK;  needs L * C * 4 < 2^31
 // ---------------------------------------------------------------------------
 template <int W0, int W1, int W2, int W3>
 __global__ void __launch_bounds__(256, 2)

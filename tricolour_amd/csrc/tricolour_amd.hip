@@ -330,15 +330,15 @@ bool st_use_fused(const StWin& sw) {
     return sw.nw == 4 && sw.w[0] == 1 && sw.w[1] == 2 && sw.w[2] == 4 && sw.w[3] == 8;
 }
 
-// The lane-mask cascade (K7c) addresses a window through 32-bit buffer
-// offsets; larger windows and TRI_ST_REGISTER=1 (tests) take the register
+// The lane-mask cascade (K7c) addresses a window through signed 32-bit buffer
+// offsets (windows below 2 GiB of float32); larger windows and TRI_ST_REGISTER=1 (tests) take the register
 // cascade (K7b).
 bool st_use_mask(int L, int C) {
     static const bool force_register = [] {
         const char* e = getenv("TRI_ST_REGISTER");
         return e && e[0] == '1';
     }();
-    return !force_register && (uint64_t)L * (uint64_t)C * 4u < (1ull << 32);
+    return !force_register && (uint64_t)L * (uint64_t)C * 4u < (1ull << 31);   // signed 32-bit scalar offsets
 }
 
 int launch_median(const Run& r, const float* data, const uint8_t* flags, double* med, size_t WSd,
@@ -1190,8 +1190,8 @@ extern "C" int tri_bench_sumthreshold(const float* data, const double* mad, uint
     size_t ws = (size_t)n_line * n_col;
     bool can_fuse = sw.nw == 4 && sw.w[0] == 1 && sw.w[1] == 2 && sw.w[2] == 4 && sw.w[3] == 8;
     if ((variant == 2 || variant == 3) && !can_fuse) return set_err(TRI_EUNSUPPORTED, "register cascade needs windows (1,2,4,8)");
-    if (variant == 3 && !((uint64_t)L * (uint64_t)C * 4u < (1ull << 32)))
-        return set_err(TRI_EUNSUPPORTED, "lane-mask cascade needs a window below 2^32 bytes");
+    if (variant == 3 && !((uint64_t)L * (uint64_t)C * 4u < (1ull << 31)))
+        return set_err(TRI_EUNSUPPORTED, "lane-mask cascade needs a window below 2^31 bytes");
     if (variant == 0 && can_fuse) variant = st_use_mask(L, C) ? 3 : 2;
     bool fused = variant == 2;
     StFusedArgs fa;
