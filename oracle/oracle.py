@@ -109,6 +109,12 @@ def make_params(ntime, nchan, **kw):
                              k["freq_chunks"], k["average_freq"])
     if len(wt) > MAX_WINDOWS or len(wf) > MAX_WINDOWS:
         raise ValueError("too many windows")
+    if int(k["num_major_iterations"]) > 0:
+        # what the reference's _sum_threshold does with such lists (flagging.py:630, 663)
+        if len(wt) == 0 or len(wf) == 0:
+            raise ValueError("zero-size array to reduction operation maximum which has no identity")
+        if (wt <= 0).any() or (wf <= 0).any():
+            raise ValueError("operands could not be broadcast together (window of size 0)")
     p = TroParams()
     p.outlier_nsigma = float(k["outlier_nsigma"])
     p.n_windows_time = len(wt)

@@ -440,3 +440,56 @@ def test_flag_dtypes_and_non_contiguous_inputs(gpu, oracle):
     assert np.array_equal(gpu.sum_threshold_flagger(amp.astype(np.float64), flags, **kw), e2)
     with pytest.raises(TypeError):
         gpu.sum_threshold_flagger(vis.astype(np.complex128), flags, **kw)
+
+
+def _random_case(rs):
+    """A random small window set + kwargs inside the reference's contract."""
+    T = int(rs.choice([1, 2, 5, 16, 31, 48, 64, 100, 130, 257, 300]))
+    F = int(rs.choice([1, 3, 16, 33, 64, 97, 128, 200, 520, 640]))
+    shape = (int(rs.randint(1, 4)), int(rs.randint(1, 3)), T, F)
+    avg = int(rs.choice([1, 1, 1, 2, 3]))
+    kw = dict(
+        outlier_nsigma=float(rs.choice([3.0, 4.5, 10.0])),
+        windows_time=[[1, 2, 4, 8], [1, 2, 4, 8], [1, 3], [2, 8, 16]][int(rs.randint(0, 4))],
+        windows_freq=[[1, 2, 4, 8], [1, 2, 4, 8], [1, 5, 9], [4]][int(rs.randint(0, 4))],
+        background_reject=float(rs.choice([2.0, 3.5])),
+        background_iterations=int(rs.choice([0, 1, 1, 2, 3])),
+        spike_width_time=float(rs.choice([0.3, 3.0, 6.5, 12.5, 20.0, 40.0])),
+        spike_width_freq=float(rs.choice([0.3, 2.0, 10.0, 18.0, 30.0])),
+        time_extend=int(rs.randint(0, 5)), freq_extend=int(rs.randint(0, 5)),
+        freq_chunks=int(rs.choice([1, 2, 5, 10])), average_freq=avg,
+        flag_all_time_frac=float(rs.choice([0.3, 0.6, 1.0])), flag_all_freq_frac=float(rs.choice([0.4, 0.8, 1.0])),
+        rho=float(rs.choice([1.3, 1.5])), num_major_iterations=int(rs.choice([1, 2, 3])))
+    vis = (rs.standard_normal(shape) + 1j * rs.standard_normal(shape)).astype(np.complex64)
+    if rs.uniform() < 0.7 and F > 4:
+        vis[..., int(rs.randint(0, F))] *= rs.choice([4.0, 9.0, 30.0])
+    if rs.uniform() < 0.7 and T > 4:
+        vis[:, :, int(rs.randint(0, T)), :] += rs.choice([3.0, 7.0])
+    if rs.uniform() < 0.3:
+        vis[rs.uniform(size=shape) < 0.01] = np.nan
+    if rs.uniform() < 0.3:
+        vis[rs.uniform(size=shape) < 0.01] = 0
+    flags = rs.uniform(size=shape) < rs.choice([0.0, 0.02, 0.3])
+    if rs.uniform() < 0.2:
+        flags[:, :, :, : max(1, F // 3)] = True
+    return vis, flags, kw
+
+
+@pytest.mark.parametrize("block", range(10))
+def test_random_cases_vs_oracle(gpu, oracle, block):
+    """Seeded sweep over shapes and kwargs (radii 0..69, odd extents, NaNs, zeros,
+    heavy pre-flagging, channel averaging, arbitrary window lists): flags bit-exact."""
+    rs = np.random.RandomState(4242 + block)
+    for k in range(20):
+        vis, flags, kw = _random_case(rs)
+        try:
+            exp = oracle.sum_threshold_flagger(vis, flags, **kw)
+        except ValueError:
+            # window lists the reference fails on (no window fits the axis, or a frequency window
+            # averaged down to size 0; flagging.py:630, 663): the product must refuse them too
+            with pytest.raises(ValueError):
+                gpu.sum_threshold_flagger(vis, flags, **kw)
+            continue
+        out = gpu.sum_threshold_flagger(vis, flags, **kw)
+        assert np.array_equal(out, exp), "block %d case %d shape %s kw %s: %d flags differ" % (
+            block, k, vis.shape, kw, int((out != exp).sum()))

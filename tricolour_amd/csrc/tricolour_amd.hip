@@ -103,10 +103,16 @@ int make_plan(int64_t T, int64_t F, const tri_params* p, Plan* pl) {
     if (pl->r0max > (1 << 20) || pl->r1max > (1 << 20)) return set_err(TRI_EUNSUPPORTED, "spike width too large");
     pl->PT = T + 4 * pl->r0max;
     pl->PF = pl->Fa + 4 * pl->r1max;
-    int rc = make_stwin(p->windows_time, p->n_windows_time, p->rho, &pl->swT);
-    if (rc) return rc;
-    rc = make_stwin(p->windows_freq, p->n_windows_freq, p->rho, &pl->swF);
-    if (rc) return rc;
+    // with no major iteration the reference never looks at its window lists
+    int rc = TRI_OK;
+    memset(&pl->swT, 0, sizeof(pl->swT));
+    memset(&pl->swF, 0, sizeof(pl->swF));
+    if (p->num_major_iterations > 0) {
+        rc = make_stwin(p->windows_time, p->n_windows_time, p->rho, &pl->swT);
+        if (rc) return rc;
+        rc = make_stwin(p->windows_freq, p->n_windows_freq, p->rho, &pl->swF);
+        if (rc) return rc;
+    }
     if (T * pl->Fa >= ((int64_t)1 << 31) || T * F >= ((int64_t)1 << 31))
         return set_err(TRI_EUNSUPPORTED, "a single window must hold fewer than 2^31 samples");
     return TRI_OK;
