@@ -353,6 +353,52 @@ __global__ void k_prepare4(const void* __restrict__ vis, const uint8_t* __restri
     reinterpret_cast<uchar4*>(flags)[i] = make_uchar4(of[0], of[1], of[2], of[3]);
 }
 
+// Amplitudes of a batch, computed ONCE per call when no channel averaging is
+// requested: |vis| does not change between major iterations, only the flags
+// do.  A NaN amplitude is flagged by every iteration's _average_freq
+// (flagging.py:856-861), so it is folded into the running flags here.  The
+// time-axis filter masks flagged samples itself (its flags contain the running
+// flags); the FT copy is masked in place by k_zero_flagged4 every iteration --
+// the running flags only grow, so zeros once written stay valid
+// (flagged -> sum 0, count 0 -> value 0, flagging.py:858-870).
+template <int VD>
+__global__ void k_amplitude4(const void* __restrict__ vis, float* __restrict__ ampl,
+                             uint8_t* __restrict__ iter, size_t n4) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // group of 4 samples, flat over the batch
+    if (i >= n4) return;
+    float a[4];
+    if (VD == TRI_VIS_C64) {
+        float4 z0 = reinterpret_cast<const float4*>(vis)[2 * i];
+        float4 z1 = reinterpret_cast<const float4*>(vis)[2 * i + 1];
+        a[0] = tri_hypotf(z0.x, z0.y); a[1] = tri_hypotf(z0.z, z0.w);
+        a[2] = tri_hypotf(z1.x, z1.y); a[3] = tri_hypotf(z1.z, z1.w);
+    } else {
+        float4 z = reinterpret_cast<const float4*>(vis)[i];
+        a[0] = fabsf(z.x); a[1] = fabsf(z.y); a[2] = fabsf(z.z); a[3] = fabsf(z.w);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) a[k] = (0.0f + a[k]) / 1.0f;   // factor 1: sum = 0 + a, count 1 (flagging.py:858-870)
+    reinterpret_cast<float4*>(ampl)[i] = make_float4(a[0], a[1], a[2], a[3]);
+    const unsigned nanb = (isnan(a[0]) ? 1u : 0u) | (isnan(a[1]) ? 0x100u : 0u) | (isnan(a[2]) ? 0x10000u : 0u) |
+                          (isnan(a[3]) ? 0x1000000u : 0u);
+    if (nanb) reinterpret_cast<unsigned*>(iter)[i] |= nanb;
+}
+
+// data[i] = 0 where flags[i] != 0, four samples per thread; groups without a flag
+// cost one byte-quad read and nothing else
+__global__ void k_zero_flagged4(const uint8_t* __restrict__ flags, float* __restrict__ data, size_t n4per,
+                                size_t ws_flags, size_t ws_data) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4per) return;
+    size_t win = blockIdx.y;
+    const unsigned f = reinterpret_cast<const unsigned*>(flags + win * ws_flags)[i];
+    if (f == 0) return;
+    float4* pd = reinterpret_cast<float4*>(data + win * ws_data) + i;
+    float4 d = *pd;
+    *pd = make_float4((f & 0xFFu) ? 0.0f : d.x, (f & 0xFF00u) ? 0.0f : d.y, (f & 0xFF0000u) ? 0.0f : d.z,
+                      (f & 0xFF000000u) ? 0.0f : d.w);
+}
+
 // OP 0: b = a   OP 1: b |= a   OP 2: b = (a != 0)     (16 bytes per thread)
 template <int OP>
 __global__ void k_u8_op16(const uint8_t* __restrict__ a, uint8_t* __restrict__ b, size_t n16per,

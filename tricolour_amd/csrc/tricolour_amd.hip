@@ -323,6 +323,10 @@ struct Run {
     const tri_params* p;
     int64_t Wb;      // windows in this batch
     Debug* dbg;      // taps of window 0 (tests only), or NULL
+    // true: ws.dataTF holds the batch's UNMASKED amplitudes, computed once (k_amplitude4,
+    // NaNs folded into the running flags; the time-axis filter masks by its own flags),
+    // ws.dataFT their transpose, masked in place every iteration (the flags only grow)
+    bool ampl_cached = false;
 };
 
 // The register cascade covers windows exactly (1,2,4,8) in that order; the
@@ -902,15 +906,26 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
     int rc;
 
     // flagging.py:756  _average_freq
-    if (pl.vec)
-        hipLaunchKernelGGL(k_prepare4<VD>, dim3((unsigned)cdiv(N * (size_t)W / 4, 256)), dim3(256), 0, r.st, vis, iter_flags, ws.dataTF, ws.flagsTF, N * (size_t)W / 4);
-    else
-        hipLaunchKernelGGL(k_prepare<VD>, grid1(N, W), dim3(256), 0, r.st, vis, iter_flags, ws.dataTF, ws.flagsTF, T, F, Fa, (int)pl.avg);
-    LAUNCHCHK();
-    rc = launch_transpose<float>(r, ws.dataTF, ws.dataFT, T, Fa, N, N, W);
-    if (rc) return rc;
+    if (r.ampl_cached) {
+        // amplitudes (both layouts) were made once for the batch; this iteration's
+        // flags = running flags (NaNs already folded in)
+        rc = launch_u8<0>(r, iter_flags, ws.flagsTF, N, N, N, W);
+        if (rc) return rc;
+    } else {
+        if (pl.vec)
+            hipLaunchKernelGGL(k_prepare4<VD>, dim3((unsigned)cdiv(N * (size_t)W / 4, 256)), dim3(256), 0, r.st, vis, iter_flags, ws.dataTF, ws.flagsTF, N * (size_t)W / 4);
+        else
+            hipLaunchKernelGGL(k_prepare<VD>, grid1(N, W), dim3(256), 0, r.st, vis, iter_flags, ws.dataTF, ws.flagsTF, T, F, Fa, (int)pl.avg);
+        LAUNCHCHK();
+        rc = launch_transpose<float>(r, ws.dataTF, ws.dataFT, T, Fa, N, N, W);
+        if (rc) return rc;
+    }
     rc = launch_transpose<uint8_t>(r, ws.flagsTF, ws.flagsFT, T, Fa, N, N, W);
     if (rc) return rc;
+    if (r.ampl_cached) {
+        hipLaunchKernelGGL(k_zero_flagged4, grid1(N / 4, W), dim3(256), 0, r.st, ws.flagsFT, ws.dataFT, N / 4, N, N);
+        LAUNCHCHK();
+    }
 
     // flagging.py:944  _time_median: rows of the FT layout are contiguous in time
     rc = launch_median(r, ws.dataFT, ws.flagsFT, ws.med, N, N, (size_t)T, 1, ws.segT_start, ws.segT_len, Fa, 1, W, pl.T, false, T % 4 == 0, true);
@@ -1012,7 +1027,10 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
     double row_limit = p->flag_all_freq_frac * (double)F;
     double col_limit = (double)T * p->flag_all_time_frac;
     if (pl.vec)
-        hipLaunchKernelGGL(k_final16<VD>, grid1(NF / 16, W), dim3(256), 0, r.st, ws.dil, ws.rowcnt, ws.colcnt, vis, out_flags, iter_flags, T, F / 16, row_limit, col_limit, update_iter ? 1 : 0);
+        if (r.ampl_cached)   // isnan(|vis|) from the cached amplitudes: half the bytes of the complex visibilities
+            hipLaunchKernelGGL(k_final16<TRI_VIS_F32>, grid1(NF / 16, W), dim3(256), 0, r.st, ws.dil, ws.rowcnt, ws.colcnt, (const void*)ws.dataTF, out_flags, iter_flags, T, F / 16, row_limit, col_limit, update_iter ? 1 : 0);
+        else
+            hipLaunchKernelGGL(k_final16<VD>, grid1(NF / 16, W), dim3(256), 0, r.st, ws.dil, ws.rowcnt, ws.colcnt, vis, out_flags, iter_flags, T, F / 16, row_limit, col_limit, update_iter ? 1 : 0);
     else
         hipLaunchKernelGGL(k_final<VD>, grid1(NF, W), dim3(256), 0, r.st, ws.dil, ws.rowcnt, ws.colcnt, vis, out_flags, iter_flags, T, F, row_limit, col_limit, update_iter ? 1 : 0);
     LAUNCHCHK();
@@ -1074,6 +1092,20 @@ int flagger_impl(const void* vis, int vis_dtype, const uint8_t* flags, uint8_t* 
         // flagging.py:1182  iter_flags = flags.copy()  (non-zero = flagged)
         rc = launch_u8<2>(r, flags + (size_t)w0 * NF, r.ws.iter, NF, NF, NF, r.Wb);
         if (rc) return rc;
+        // without channel averaging |vis| is the same in every major iteration:
+        // compute it once, in both layouts (TRI_NO_AMPL_CACHE=1 recomputes it per iteration)
+        static const bool no_cache = [] { const char* e = getenv("TRI_NO_AMPL_CACHE"); return e && e[0] == '1'; }();
+        r.ampl_cached = r.pl.vec && !no_cache && p->num_major_iterations > 0;
+        if (r.ampl_cached) {
+            const size_t n4 = (size_t)r.Wb * NF / 4;
+            if (vis_dtype == TRI_VIS_C64)
+                hipLaunchKernelGGL(k_amplitude4<TRI_VIS_C64>, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, r.st, (const void*)vis_b, r.ws.dataTF, r.ws.iter, n4);
+            else
+                hipLaunchKernelGGL(k_amplitude4<TRI_VIS_F32>, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, r.st, (const void*)vis_b, r.ws.dataTF, r.ws.iter, n4);
+            LAUNCHCHK();
+            rc = launch_transpose<float>(r, r.ws.dataTF, r.ws.dataFT, (int)T, (int)r.pl.Fa, NF, NF, r.Wb);
+            if (rc) return rc;
+        }
         for (int64_t it = 0; it < p->num_major_iterations; it++) {
             bool last = it == p->num_major_iterations - 1;
             bool tap = last && w0 == 0;
