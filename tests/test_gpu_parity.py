@@ -1,6 +1,8 @@
 """Parity tests proper: the HIP path (through the C ABI) against the oracle
 on the same inputs.  Flags must be bit-exact; float32 intermediates must be
 bit-identical too (the kernels follow the reference's evaluation order)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -493,3 +495,43 @@ def test_random_cases_vs_oracle(gpu, oracle, block):
         out = gpu.sum_threshold_flagger(vis, flags, **kw)
         assert np.array_equal(out, exp), "block %d case %d shape %s kw %s: %d flags differ" % (
             block, k, vis.shape, kw, int((out != exp).sum()))
+
+
+ALT_PATH_SCRIPT = r'''
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+import tricolour_amd
+from oracle import oracle
+rs = np.random.RandomState(77)
+bad = 0
+for shape, kw in (((2, 1, 64, 128), dict(num_major_iterations=2)),
+                  ((1, 2, 100, 144), dict(num_major_iterations=2, background_iterations=2, spike_width_time=20.0,
+                                          spike_width_freq=15.0)),
+                  ((1, 1, 52, 300), dict(num_major_iterations=1, windows_freq=[1, 2, 4, 8, 16]))):
+    vis = (rs.standard_normal(shape) + 1j * rs.standard_normal(shape)).astype(np.complex64)
+    vis[..., shape[3] // 3] *= 8
+    vis[:, :, shape[2] // 2, :] += 5
+    vis[0, 0, 3, 5] = np.nan
+    flags = rs.uniform(size=shape) < 0.03
+    out = tricolour_amd.sum_threshold_flagger(vis, flags, **kw)
+    exp = oracle.sum_threshold_flagger(vis, flags, **kw)
+    bad += int((out != exp).sum())
+print("DIFF", bad)
+'''
+
+
+@pytest.mark.parametrize("knob", ["TRI_NO_AMPL_CACHE", "TRI_FILTER_NO_FUSED_DIV", "TRI_FILTER_NO_TIN", "TRI_FILTER_NO_LANE4",
+                                  "TRI_NO_PACKED_FLAGS", "TRI_FILTER_MULTIPASS", "TRI_ST_GENERIC", "TRI_ST_REGISTER",
+                                  "TRI_FILTER_DIRECT_FT"])
+def test_alternate_kernel_paths(gpu, knob):
+    """Every fallback / A-B path selectable through an environment knob (read once
+    per process, hence the subprocess) stays bit-exact against the oracle."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ)
+    env[knob] = "1"
+    p = subprocess.run([sys.executable, "-c", ALT_PATH_SCRIPT % ROOT], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "DIFF 0" in p.stdout, p.stdout + p.stderr
