@@ -258,20 +258,26 @@ k_median_wave(const float* __restrict__ data, const uint8_t* __restrict__ flags,
         if (keys[u] != SENT) keys[u] -= kmin;
     unsigned prefix = 0, pmask = 0, kk = n >> 1;
     unsigned* h = hist[wave];
-    for (int p = 0; p < 4; p++) {
+    // Each wave owns its histogram and LDS operations of one wave execute in
+    // order, so the passes need no workgroup barrier (the four segments of a
+    // workgroup differ in sample count and digit count): a wave-level fence
+    // keeps the compiler from reordering around the atomics.
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    for (int p = 0; p < P; p++) {
         const int shift = max(B - 8 * (p + 1), 0);
-        const bool act = p < P;
         reinterpret_cast<uint4*>(h)[lane] = make_uint4(0, 0, 0, 0);
-        __syncthreads();
-        if (act) {
+        wave_sync();
 #pragma unroll
-            for (int u = 0; u < KS; u++) {
-                unsigned k = keys[u];
-                if (k != SENT && (k & pmask) == prefix) atomicAdd(&h[(k >> shift) & 0xFFu], 1u);
-            }
+        for (int u = 0; u < KS; u++) {
+            unsigned k = keys[u];
+            if (k != SENT && (k & pmask) == prefix) atomicAdd(&h[(k >> shift) & 0xFFu], 1u);
         }
-        __syncthreads();
-        if (act) {
+        wave_sync();
+        {
             uint4 hv = reinterpret_cast<uint4*>(h)[lane];
             unsigned sacc = hv.x + hv.y + hv.z + hv.w;
             unsigned inc = sacc;
@@ -299,7 +305,7 @@ k_median_wave(const float* __restrict__ data, const uint8_t* __restrict__ flags,
             }
             pmask |= 0xFFu << shift;
         }
-        __syncthreads();
+        wave_sync();
     }
     unsigned cnt = 0, mx = 0;
 #pragma unroll
