@@ -257,6 +257,33 @@ int tri_bench_sumthreshold(const float *data, const double *mad, uint8_t *out,
                            int repeats, float *ms_per_launch, void *stream);
 
 /*
+ * tri_bench_boxfilter runs ONE axis stage of masked_gaussian_filter's two box
+ * filters (flagging.py:362-419, 469-513) `repeats` times on `stream` in the
+ * launch geometry the flagger itself uses, bracketed by HIP events on that
+ * stream; mean time per stage in `ms_per_launch`.
+ *   stage 0: time-axis stage.  data (n_win, n_line, n_col) float32, line axis
+ *            = time, columns coalesced; flags4 the same window's flags packed
+ *            four line positions per 32-bit word, (n_win, n_line / 4, n_col)
+ *            words; out_w / out_o (n_win, n_line, n_col) receive the filtered
+ *            weight (!flag) and weight * data images, already divided by
+ *            float32(2 r + 1) ** 4.
+ *   stage 1: frequency-axis stage fused with the masked division of the
+ *            rejection loop (flagging.py:506-513, 563-566).  Here the line axis
+ *            of the INPUT is its contiguous one: `flags4` is reinterpreted as
+ *            the float32 weight image and `data` as the weight * data image,
+ *            both (n_win, n_line, n_col) with n_col positions per line; `data`
+ *            also stands in for the (n_col, n_line) amplitude image; out_o
+ *            (n_win, n_col, n_line) receives |data - background|, out_w is
+ *            scratch.
+ * `variant`: 0 = the flagger's default route for this radius, 1 = LDS delay
+ * lines only (K4b / K4c / multi-pass), 2 = register delay lines (K4r).
+ */
+int tri_bench_boxfilter(const float *data, const uint8_t *flags4, float *out_w,
+                        float *out_o, int64_t n_win, int64_t n_line, int64_t n_col,
+                        int64_t radius, int stage, int variant, int repeats,
+                        float *ms_per_launch, void *stream);
+
+/*
  * Test hook: tri_sum_threshold_flagger that additionally taps the LAST major
  * iteration's intermediates of window 0 into caller-provided device buffers
  * (Fa = averaged channels, N = ntime * Fa):

@@ -322,6 +322,74 @@ def test_full_size_window_vs_oracle(gpu, oracle):
     assert nbad == 0, "%d of %d flags differ" % (nbad, out.size)
 
 
+# The shipped strategy file's two heaviest parameter sets (conf/default.yaml:20-35 and :59-73),
+# restated here because the reference tree does not travel to the GPU box.
+SHIPPED_KWARGS = {
+    # "background_flags": box radii [54,43] [43,34] [32,25] [21,17] [10,8] (lane-per-stage and
+    # four-ring filters on 1024- / 4096-long lines), two of the five major iterations
+    "stage1": dict(outlier_nsigma=10, windows_time=[1, 2, 4, 8], windows_freq=[1, 2, 4, 8],
+                   background_reject=2.0, background_iterations=5, spike_width_time=12.5,
+                   spike_width_freq=10.0, time_extend=3, freq_extend=3, freq_chunks=10,
+                   average_freq=1, flag_all_time_frac=0.6, flag_all_freq_frac=0.8, rho=1.3,
+                   num_major_iterations=2),
+    # "final_st_very_broad": frequency radii 277 / 221 / 166 / 110 / 55 (the first three take the
+    # in-place multi-pass filter by the default route), frequency windows 32...128 (generic
+    # SumThreshold kernel on full lines)
+    "very_broad": dict(outlier_nsigma=10, windows_time=[1, 2, 4, 8],
+                       windows_freq=[32, 48, 64, 128], background_reject=2.0,
+                       background_iterations=5, spike_width_time=6.5, spike_width_freq=64.0,
+                       time_extend=3, freq_extend=3, freq_chunks=10, average_freq=1,
+                       flag_all_time_frac=0.6, flag_all_freq_frac=0.8, rho=1.3,
+                       num_major_iterations=1),
+}
+
+
+def _full_size_inputs(seed):
+    rs = np.random.RandomState(seed)
+    shape = (1, 2, 1024, 4096)
+    vis = np.empty(shape, np.complex64)
+    vis.real = rs.standard_normal(shape).astype(np.float32)
+    vis.imag = rs.standard_normal(shape).astype(np.float32)
+    vis.real[..., ::97] += 8.0                      # bad channels
+    vis.real[:, :, ::211, :] += 6.0                 # bad times
+    vis.real[0, 0, 100:140, 2000:2300] += 2.0       # broad-band block
+    vis.real[0, 1, :, 3000:3060] += 1.5             # faint wide feature (broad windows)
+    idx = rs.randint(0, vis.size, 500)
+    vis.real.reshape(-1)[idx] += 50.0
+    vis.real.reshape(-1)[rs.randint(0, vis.size, 50)] = np.nan
+    flags = np.zeros(shape, np.bool_)
+    flags[..., ::50] = True
+    flags[0, 1, 300:320, :] = True
+    flags[0, 0, :, 1200:1900] = True                # 700 flagged channels: wider than any filter support but r = 277 x 4
+    return vis, flags
+
+
+@pytest.mark.parametrize("name", sorted(SHIPPED_KWARGS))
+def test_full_size_shipped_kwargs_vs_oracle(gpu, oracle, name):
+    """One 1024 x 4096 window pair per shipped parameter set through the DEFAULT kernel
+    routes, flags and the six last-iteration intermediates bit-for-bit against the
+    canonical oracle (flagging.py:422-466, 610-681)."""
+    vis, flags = _full_size_inputs(7 if name == "stage1" else 8)
+    kw = SHIPPED_KWARGS[name]
+    dbg = {}
+    out = gpu.sum_threshold_flagger(vis, flags, _debug=dbg, **kw)
+    exp, inter = oracle.sum_threshold_flagger(vis, flags, n_threads=2, dump=True, **kw)
+    report = []
+    for k in ("spec_resid", "background", "residual"):
+        bad = int((~_same_f32(inter[k], dbg[k])).sum())
+        if bad:
+            report.append("%s: %d float32 words differ" % (k, bad))
+    for k in ("spec_flags", "time_flags", "freq_flags"):
+        bad = int((inter[k].astype(bool) != dbg[k].reshape(inter[k].shape)).sum())
+        if bad:
+            report.append("%s: %d flags differ" % (k, bad))
+    bad = int((out != exp).sum())
+    if bad:
+        report.append("out: %d of %d flags differ" % (bad, out.size))
+    assert not report, "%s: %s" % (name, "; ".join(report))
+    assert 0 < out.mean() < 1
+
+
 def test_size_independent_properties_at_slab_scale(gpu):
     """Properties that need no oracle, on a multi-GB slab: determinism,
     independence of a window's result from its batch neighbours, all-flagged

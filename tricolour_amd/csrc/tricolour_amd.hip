@@ -9,6 +9,7 @@
 #include "kernels_elementwise.hpp"
 #include "kernels_median.hpp"
 #include "kernels_boxfilter.hpp"
+#include "kernels_boxline.hpp"
 #include "kernels_sumthreshold.hpp"
 
 // ===========================================================================
@@ -438,6 +439,63 @@ inline bool colfilter_use_lane4(int rad) {
 // `deferred_denom` (optional): when the single-sweep kernel is used the final
 // division by float32(d)**4 is left to the consumer (transpose / masked_div) and
 // *deferred_denom receives the denominator; otherwise it is set to 0.
+// Register-ring single sweep (K4r, kernels_boxline.hpp): KS register slots per stage, the
+// rest of the 2r-deep delay line in LDS.  Returns 0 when the radius is outside its range.
+// TRI_FILTER_NO_REGRING=1 keeps the LDS-ring kernels (A/B runs, tests).
+#ifndef BOXR_MAX_LDS_SLOTS
+#define BOXR_MAX_LDS_SLOTS 60
+#endif
+thread_local int g_boxr_override = -1;     // measurement hook: 0 = LDS-ring kernels, 1 = register-ring kernels
+int boxr_pick_ks(int rad) {
+    static const bool env_off = [] { const char* e = getenv("TRI_FILTER_NO_REGRING"); return e && e[0] == '1'; }();
+    const bool off = g_boxr_override >= 0 ? g_boxr_override == 0 : env_off;
+    if (off || rad < 4 || rad > 107) return 0;
+    const int ks = 2 * rad >= 80 ? 80 : (2 * rad >= 64 ? 64 : (2 * rad >= 32 ? 32 : (2 * rad >= 16 ? 16 : 8)));
+    return 2 * rad - ks <= BOXR_MAX_LDS_SLOTS ? ks : 0;
+}
+
+// the time-axis stage keeps K4b below 16 slots (already at the HBM floor there); the fused
+// frequency stage takes the register form from r = 4 on
+int boxr_pick_ks_t(int rad) { return 2 * rad >= 32 ? boxr_pick_ks(rad) : 0; }
+int boxr_pick_ks_f(int rad) {
+    static const bool off = [] { const char* e = getenv("TRI_FILTER_NO_REGRING_F"); return e && e[0] == '1'; }();
+    return off ? 0 : boxr_pick_ks(rad);
+}
+
+template <int KS>
+int launch_boxt_ks(const Run& r, const float* srcData, const uint8_t* srcFlags, float* dstW, float* dstO,
+                   int n, int C, int rad, float denom, size_t sws, size_t dws, int64_t W) {
+    const int d = 2 * rad - KS;
+    const size_t lds = (size_t)4 * d * 64 * sizeof(float);
+    dim3 grid((unsigned)cdiv(C, 64), (unsigned)W);
+    static const hipError_t attr = [] {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boxt<KS, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boxt<KS, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return e;
+    }();
+    HIPCHK(attr);
+    // one launch per image: a compute unit then runs (mostly) one of the two long loop bodies at a time
+    if (d > 0) {
+        hipLaunchKernelGGL((k_boxt<KS, true, 0>), grid, dim3(64), lds, r.st, srcData, srcFlags, dstW, n, C, rad, denom, sws, dws);
+        hipLaunchKernelGGL((k_boxt<KS, true, 1>), grid, dim3(64), lds, r.st, srcData, srcFlags, dstO, n, C, rad, denom, sws, dws);
+    } else {
+        hipLaunchKernelGGL((k_boxt<KS, false, 0>), grid, dim3(64), 0, r.st, srcData, srcFlags, dstW, n, C, rad, denom, sws, dws);
+        hipLaunchKernelGGL((k_boxt<KS, false, 1>), grid, dim3(64), 0, r.st, srcData, srcFlags, dstO, n, C, rad, denom, sws, dws);
+    }
+    LAUNCHCHK();
+    return TRI_OK;
+}
+
+int launch_boxt(const Run& r, int ks, const float* srcData, const uint8_t* srcFlags, float* dstW, float* dstO,
+                int n, int C, int rad, float denom, size_t sws, size_t dws, int64_t W) {
+    switch (ks) {
+        case 32: return launch_boxt_ks<32>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
+        case 64: return launch_boxt_ks<64>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
+        case 80: return launch_boxt_ks<80>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
+    }
+    return set_err(TRI_EINVAL, "no register-ring kernel for %d slots", ks);
+}
+
 int launch_colfilter(const Run& r, int srcmode, float* bufW, float* bufO, const float* srcData,
                      const uint8_t* srcFlags, float* dstW, float* dstO, int n, int C, int rad,
                      size_t bws, size_t sws, size_t dws, int64_t W, float* deferred_denom = nullptr,
@@ -447,6 +505,9 @@ int launch_colfilter(const Run& r, int srcmode, float* bufW, float* bufO, const 
     const int intw = (weights_are_01 && rad <= 31) ? 1 : 0;
     int bt = colfilter_lds_block(rad, C);
     if (deferred_denom) *deferred_denom = 0.0f;
+    if (srcmode == 2 && !deferred_denom && !transposed_out && weights_are_01 && boxr_pick_ks_t(rad) > 0 &&
+        n % 4 == 0 && (uint64_t)n * (uint64_t)C * 4u < (1ull << 31))   // signed 32-bit buffer offsets
+        return launch_boxt(r, boxr_pick_ks_t(rad), srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
     if (bt > 0 && colfilter_use_lane4(rad) && !transposed_out) {
         size_t lds = (size_t)lane4_ring_capacity(rad) * 64 * sizeof(float);
         dim3 grid((unsigned)cdiv(C, 16), (unsigned)W, 2);
@@ -674,6 +735,40 @@ int launch_colfilter_tf(const Run& r, const float* srcW, const float* srcO, floa
     return TRI_OK;
 }
 
+// Register-ring form of the fused stage (K4r, k_boxf): any radius boxr_pick_ks() accepts.
+template <int KS, int MODE>
+int launch_boxf_ks(const Run& r, const float* srcW, const float* srcO, float* dstW, float* dstO, const float* data,
+                   int n, int C, int ld, int rad, size_t sws_img, size_t dws, size_t ws_data, int64_t W, uint8_t* nanflag) {
+    const float denom = box_denominator(rad);
+    const int d = 2 * rad - KS;
+    const size_t lds = (size_t)2 * ((size_t)4 * d * 64 + (size_t)boxr_pf(KS) * 65) * sizeof(float);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boxf<KS, true, MODE>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    HIPCHK(attr);
+    dim3 grid((unsigned)cdiv(C, 64), (unsigned)W);
+    if (d > 0)
+        hipLaunchKernelGGL((k_boxf<KS, true, MODE>), grid, dim3(128), lds, r.st, srcW, srcO, dstW, dstO, data, n, C, ld, rad,
+                           denom, sws_img, dws, ws_data, nanflag);
+    else
+        hipLaunchKernelGGL((k_boxf<KS, false, MODE>), grid, dim3(128), lds, r.st, srcW, srcO, dstW, dstO, data, n, C, ld, rad,
+                           denom, sws_img, dws, ws_data, nanflag);
+    LAUNCHCHK();
+    return TRI_OK;
+}
+
+template <int MODE>
+int launch_boxf(const Run& r, int ks, const float* srcW, const float* srcO, float* dstW, float* dstO, const float* data,
+                int n, int C, int ld, int rad, size_t sws_img, size_t dws, size_t ws_data, int64_t W, uint8_t* nanflag) {
+    switch (ks) {
+        case 8: return launch_boxf_ks<8, MODE>(r, srcW, srcO, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
+        case 16: return launch_boxf_ks<16, MODE>(r, srcW, srcO, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
+        case 32: return launch_boxf_ks<32, MODE>(r, srcW, srcO, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
+        case 64: return launch_boxf_ks<64, MODE>(r, srcW, srcO, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
+        case 80: return launch_boxf_ks<80, MODE>(r, srcW, srcO, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
+    }
+    return set_err(TRI_EINVAL, "no register-ring kernel for %d slots", ks);
+}
+
 // Lane-per-stage variant of the same (radii 17..LANE4_R_MAX): k_colfilter_lane4<3, *>.
 bool colfilter_t4_usable(int rad) {
     static const bool off = [] { const char* e = getenv("TRI_FILTER_NO_TIN"); return e && e[0] == '1'; }();
@@ -783,8 +878,10 @@ int background2d(const Run& r) {
         float den_t = 0.0f, den_f = 0.0f;   // divisions deferred to the transposes / masked_div
         bool direct_ft = false;
         // frequency stage able to read the time stage's TF images itself (no transposes)
-        const bool tin4 = !colfilter_t_usable(r1) && colfilter_t4_usable(r1);
-        const bool tin = colfilter_t_usable(r1) || tin4;
+        // register-ring fused frequency stage (signed 32-bit buffer offsets: window below 2^31 bytes)
+        const int ksf = ((uint64_t)N * 4u < (1ull << 31) && (uint64_t)wsA * 4u < (1ull << 31)) ? boxr_pick_ks_f(r1) : 0;
+        const bool tin4 = !ksf && !colfilter_t_usable(r1) && colfilter_t4_usable(r1);
+        const bool tin = ksf > 0 || colfilter_t_usable(r1) || tin4;
         float* den_t_ptr = tin ? nullptr : &den_t;
         // (for the in-place multi-pass kernel, used at large radii, building on
         //  the fly measured faster: 11.4 vs 16.8 ms per call at 128 windows)
@@ -834,13 +931,15 @@ int background2d(const Run& r) {
         //     in-place multi-pass filter, rows [0, Fa) for the single-sweep one ---
         size_t off = colfilter_lds_block(r1, T) > 0 ? 0 : (size_t)4 * r1 * T;
         // frequency stage + masked division in one kernel when the four-ring stage applies
-        const bool fused_div = tin && !tin4 && !direct_ft && colfilter_tf_usable(r1);
+        const bool fused_div = tin && !tin4 && !direct_ft && (ksf > 0 || colfilter_tf_usable(r1));
         if (fused_div) {
             if (final_pass) {
                 HIPCHK(hipMemsetAsync(ws.rowcnt, 0, (size_t)W * T, r.st));
-                rc = launch_colfilter_tf<2>(r, ws.Aw, ws.Ao, ws.Bw, ws.Bo, ws.dataFT, Fa, T, Fa, r1, wsA, wsB, N, W, reinterpret_cast<uint8_t*>(ws.rowcnt));
+                if (ksf) rc = launch_boxf<2>(r, ksf, ws.Aw, ws.Ao, ws.Bw, ws.Bo, ws.dataFT, Fa, T, Fa, r1, wsA, wsB, N, W, reinterpret_cast<uint8_t*>(ws.rowcnt));
+                else rc = launch_colfilter_tf<2>(r, ws.Aw, ws.Ao, ws.Bw, ws.Bo, ws.dataFT, Fa, T, Fa, r1, wsA, wsB, N, W, reinterpret_cast<uint8_t*>(ws.rowcnt));
             } else {
-                rc = launch_colfilter_tf<1>(r, ws.Aw, ws.Ao, ws.Bw, ws.Bo, ws.dataFT, Fa, T, Fa, r1, wsA, wsB, N, W, nullptr);
+                if (ksf) rc = launch_boxf<1>(r, ksf, ws.Aw, ws.Ao, ws.Bw, ws.Bo, ws.dataFT, Fa, T, Fa, r1, wsA, wsB, N, W, nullptr);
+                else rc = launch_colfilter_tf<1>(r, ws.Aw, ws.Ao, ws.Bw, ws.Bo, ws.dataFT, Fa, T, Fa, r1, wsA, wsB, N, W, nullptr);
             }
             if (rc) return rc;
         } else if (tin && !direct_ft) {
@@ -1254,6 +1353,64 @@ extern "C" int tri_bench_sumthreshold(const float* data, const double* mad, uint
     (void)hipFree(ring);
     (void)hipFree(acc);
     (void)hipFree(d_ends);
+    return TRI_OK;
+}
+
+// Measurement / test hook: one axis stage of the masked box filter in the launch geometry of
+// the step (see include/tricolour_amd.h).
+extern "C" int tri_bench_boxfilter(const float* data, const uint8_t* flags4, float* out_w, float* out_o,
+                                   int64_t n_win, int64_t n_line, int64_t n_col, int64_t radius,
+                                   int stage, int variant, int repeats, float* ms_per_launch, void* stream) {
+    if (!data || !flags4 || !out_w || !out_o || !ms_per_launch) return set_err(TRI_EINVAL, "NULL pointer argument");
+    if (n_win <= 0 || n_line <= 0 || n_col <= 0 || repeats <= 0 || n_win > 65535 || radius <= 0 || n_line % 4 != 0)
+        return set_err(TRI_EINVAL, "bad shape");
+    if (stage != 0 && stage != 1) return set_err(TRI_EUNSUPPORTED, "stage must be 0 or 1");
+    if (variant < 0 || variant > 2) return set_err(TRI_EINVAL, "variant must be 0, 1 or 2");
+    Run r;
+    r.st = (hipStream_t)stream;
+    r.p = nullptr;
+    r.dbg = nullptr;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    const size_t N = (size_t)n_line * n_col;
+    g_boxr_override = variant == 0 ? -1 : (variant == 1 ? 0 : 1);
+    int rc = TRI_OK;
+    HIPCHK(hipEventRecord(e0, r.st));
+    for (int i = 0; i < repeats && rc == TRI_OK; i++) {
+        if (stage == 0) {
+            rc = launch_colfilter(r, 2, out_w, out_o, data, flags4, out_w, out_o, (int)n_line, (int)n_col, (int)radius, N, N, N,
+                                  n_win, nullptr, false, true);
+        } else {
+            // frequency-axis stage + masked division from TF images (line = time row, n_col positions):
+            // the flagger's route for this radius (fused register / LDS ring kernel, or lane-per-stage
+            // filter followed by the division kernel)
+            const float* srcW = reinterpret_cast<const float*>(flags4);
+            const int T = (int)n_line, Fa = (int)n_col, rad = (int)radius;
+            const int ksf = boxr_pick_ks_f(rad);
+            if (ksf > 0) {
+                rc = launch_boxf<1>(r, ksf, srcW, data, out_w, out_o, data, Fa, T, Fa, rad, N, N, N, n_win, nullptr);
+            } else if (colfilter_tf_usable(rad)) {
+                rc = launch_colfilter_tf<1>(r, srcW, data, out_w, out_o, data, Fa, T, Fa, rad, N, N, N, n_win, nullptr);
+            } else if (colfilter_t4_usable(rad)) {
+                float den_f = 0.0f;
+                rc = launch_colfilter_t4(r, srcW, data, out_w, out_o, Fa, T, Fa, rad, N, N, n_win, &den_f);
+                if (rc == TRI_OK) rc = launch_masked_div<1>(r, out_w, out_o, data, N, N, N, n_win, den_f);
+            } else {
+                rc = set_err(TRI_EUNSUPPORTED, "no single-sweep frequency stage for radius %d", rad);
+            }
+        }
+    }
+    g_boxr_override = -1;
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(e1, r.st));
+    HIPCHK(hipEventSynchronize(e1));
+    LAUNCHCHK();
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *ms_per_launch = ms / repeats;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     return TRI_OK;
 }
 
