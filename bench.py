@@ -1,29 +1,40 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mvis/s flagged by sum_threshold_flagger on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload slab|chain|ska] [--params stage1|defaults|very_broad]
 
-A "step" is ONE sum_threshold_flagger call over one HBM-resident slab of the
-MeerKAT-64 configuration (BASELINE.json configs[1]: 2016 bl x 4 corr x 1024
-time x 4096 chan).  The full window set (270.6 GB of complex64 + 33.8 GB of
-flags) exceeds 288 GB of HBM, so it is processed as baseline slabs; every rank
-holds one slab of --bl baselines (weak scaling: with the default 252 baselines
-per rank, 8 ranks together hold exactly the 2016-baseline configuration =
-configs[2]).  Baselines are independent (flagging.py:765-774), so there is no
-data-path collective: ranks only meet at the timing barriers.
+Workloads (BASELINE.json configs):
+  slab   (default) one sum_threshold_flagger call per step over one HBM-resident slab of the MeerKAT-64
+         configuration (configs[1]: 2016 bl x 4 corr x 1024 time x 4096 chan).  The full window set (270.6 GB of
+         complex64 + 33.8 GB of flags) exceeds 288 GB of HBM, so it is processed as baseline slabs; every rank
+         holds one slab of --bl baselines (weak scaling: with the default 252 baselines per rank, 8 ranks
+         together hold exactly the 2016-baseline configuration = configs[2]).
+  chain  configs[3]: per step S scans (independent datasets, apps/tricolour/app.py:295-313, 370), each run
+         through flag_nans_zeros -> apply_static_mask(or) -> flag_autos -> uvcontsub_flagger -> sum_threshold
+         (stage-1 kwargs) with the executor's replace / OR rules (strat_executor.py:39-78), device-resident.
+  ska    configs[4] geometry: (bl, 2, 512, 65536) windows streamed slab by slab through two pinned host
+         buffers with H2D / kernels / D2H overlapped on three streams; a step = one slab.  `value` is the
+         device-resident rate over the same slabs; the PCIe-inclusive sustained rate is reported beside it.
 
-Prints ONE JSON line (rank 0): metric/value = whole-job Mvis/s with inputs
-already resident in HBM, plus
-  "roofline"      the fused SumThreshold column kernel, timed live with HIP
-                  events on its launch stream (tri_bench_sumthreshold);
-  "cpu_baseline"  the CPU oracle (a C restatement of the reference's numba
-                  path -- numba itself cannot run here) on a bounded sample of
-                  the same workload on this box's host cores (rank 0, N=1).
+Baselines are independent (flagging.py:765-774): ranks own contiguous baseline slabs and only meet at the
+timing barriers.  For N > 1 a separately timed leg scatters a small slab set from rank 0 and gathers the
+flags back over RCCL (tricolour_amd.distributed), which is how a single-root data set would be fanned out.
+
+`--gpus N` without a torchrun environment starts the N ranks itself (python -m torch.distributed.run ...)
+before any GPU call and relays rank 0's line.
+
+Prints ONE JSON line (rank 0): metric / value = whole-job Mvis/s with inputs already resident in HBM, plus
+  "roofline"      list: the fused SumThreshold column kernel and the box-filter stages, each timed live with
+                  HIP events on its launch stream in the step's own launch geometry;
+  "cpu_baseline"  the CPU oracle (a C restatement of the reference's numba path -- numba itself cannot run
+                  here) on a bounded sample of the same workload on this box's host cores (rank 0, N=1);
+  "other_params"  the same slab with the other shipped parameter sets (slab workload, N=1).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -36,7 +47,7 @@ if ROOT not in sys.path:
 PARAM_SETS = {
     # library defaults (flagging.py:1076-1083)
     "defaults": dict(),
-    # conf/default.yaml:20-35 "background_flags" -- the heaviest shipped stage
+    # conf/default.yaml:20-35 "background_flags" -- the heaviest shipped stage (the headline)
     "stage1": dict(outlier_nsigma=10, windows_time=[1, 2, 4, 8], windows_freq=[1, 2, 4, 8],
                    background_reject=2.0, background_iterations=5, spike_width_time=12.5,
                    spike_width_freq=10.0, time_extend=3, freq_extend=3, freq_chunks=10,
@@ -50,9 +61,20 @@ PARAM_SETS = {
                        flag_all_time_frac=0.6, flag_all_freq_frac=0.8, rho=1.3,
                        num_major_iterations=1),
 }
+# conf/default.yaml:37-45 "residual_flag_initial"
+UVCONTSUB_KW = dict(major_cycles=7, or_original_from_cycle=1, taylor_degrees=20, sigma=15.0)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ST_BYTES_PER_SAMPLE = 5  # fused SumThreshold pass: 4 B residual in + 1 B flag out
+# box filter, per axis stage of one masked filter (both images): SURVEY 8(d) prices a stage at
+# 2 arrays x (4 R + 4 W) = 16 B/sample; the fused frequency stage also reads the amplitudes (4 B) and writes one
+# image instead of two: 8 R + 4 R + 4 W = 16 B/sample
+BOX_BYTES_PER_SAMPLE = 16
+
+
+def box_radius(sigma):
+    """int(0.5 * sqrt(12 sigma^2 / passes + 1)), flagging.py:451 (passes = 4)"""
+    return int(0.5 * np.sqrt(12.0 * sigma * sigma / 4.0 + 1.0))
 
 
 def synth_slab(torch, nbl, ncorr, T, F, device, seed):
@@ -86,38 +108,62 @@ def synth_slab(torch, nbl, ncorr, T, F, device, seed):
     return vis, flags
 
 
-def cpu_baseline(kw, T, F, seconds_budget=25.0):
-    """Oracle (C restatement of the reference CPU path, OpenMP over windows)
-    on a bounded sample of the same workload."""
+def synth_host_windows(nwin, T, F, seed=1234):
+    rs = np.random.RandomState(seed)
+    vis = np.empty((nwin, 1, T, F), np.complex64)
+    vis.real = rs.standard_normal((nwin, 1, T, F)).astype(np.float32)
+    vis.imag = rs.standard_normal((nwin, 1, T, F)).astype(np.float32)
+    vis.real[..., ::97] += 8.0
+    vis.real[:, :, ::211, :] += 6.0
+    flags = np.zeros(vis.shape, np.bool_)
+    flags[..., ::50] = True
+    return vis, flags
+
+
+def cpu_baseline(kw, T, F, seconds_budget=25.0, chain=None):
+    """Oracle (C restatement of the reference CPU path, OpenMP over windows) on a bounded sample of the same
+    workload.  `chain`: also run the cheap steps and uvcontsub (numpy restatements) in front."""
     from oracle import oracle
     oracle.set_modes(oracle.POW_SQMUL, oracle.INTERP_F64)
     cores = min(os.cpu_count() or 1, 16)
-    rs = np.random.RandomState(1234)
 
-    def make(nwin):
-        vis = (rs.standard_normal((nwin, 1, T, F)) + 1j * rs.standard_normal((nwin, 1, T, F))).astype(np.complex64)
-        vis.real[..., ::97] += 8.0
-        vis.real[:, :, ::211, :] += 6.0
-        flags = np.zeros(vis.shape, np.bool_)
-        flags[..., ::50] = True
-        return vis, flags
+    def run(vis, flags, threads):
+        t0 = time.time()
+        if chain is not None:
+            f = oracle.flag_nans_and_zeros(vis, flags)
+            f = oracle.uvcontsub_flagger(vis, f, **chain)
+            out = oracle.sum_threshold_flagger(vis, f, n_threads=threads, **kw)
+            out |= f
+        else:
+            oracle.sum_threshold_flagger(vis, flags, n_threads=threads, **kw)
+        return time.time() - t0
 
     # calibrate on one window with one thread, then size the sample
-    vis, flags = make(1)
-    t0 = time.time()
-    oracle.sum_threshold_flagger(vis, flags, n_threads=1, **kw)
-    t1 = time.time() - t0
+    vis, flags = synth_host_windows(1, T, F)
+    t1 = run(vis, flags, 1)
     per_thread = max(1, int(seconds_budget / max(t1, 1e-3)))
     nwin = cores * min(per_thread, 2)
     if t1 > seconds_budget:
         nwin = cores
-    vis, flags = make(nwin)
-    t0 = time.time()
-    oracle.sum_threshold_flagger(vis, flags, n_threads=cores, **kw)
-    dt = time.time() - t0
+    vis, flags = synth_host_windows(nwin, T, F)
+    dt = run(vis, flags, cores)
+    what = "chain (flag_nans_zeros, uvcontsub, sum_threshold)" if chain is not None else "same kwargs"
     return dict(value=round(nwin * T * F / dt / 1e6, 3), unit="Mvis/s", cores=cores, kind="port",
-                sample="%d windows of %dx%d (1 corr), same kwargs, %.1f s; C restatement of the "
-                       "reference numba path (oracle/), OpenMP over windows" % (nwin, T, F, dt))
+                sample="%d windows of %dx%d (1 corr), %s, %.1f s; C restatement of the "
+                       "reference numba path (oracle/), OpenMP over windows" % (nwin, T, F, what, dt))
+
+
+def _pmc_traffic(name, samples):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes of the same launch geometry
+    (FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE); bench.py cannot collect counters itself."""
+    for fn in ("r02_pmc_%s.json" % name, "r01_pmc_%s.json" % name):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
+            if pmc.get("samples_per_launch") == samples:
+                return pmc["hbm_bytes_per_launch"], "profiles/" + fn
+        except Exception:
+            pass
+    return None, None
 
 
 def roofline_sumthreshold(torch, device, T, F, kw, nwin):
@@ -145,55 +191,281 @@ def roofline_sumthreshold(torch, device, T, F, kw, nwin):
                                               C.byref(ms), stream))
     samples = nwin * T * F
     achieved = samples * ST_BYTES_PER_SAMPLE / (ms.value * 1e-3) / 1e9
-    # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same
-    # launch geometry (FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE); bench.py
-    # cannot collect counters itself.
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_sumthreshold.json")))
-        if pmc.get("samples_per_launch") == samples:
-            traffic = pmc["hbm_bytes_per_launch"]
-    except Exception:
-        traffic = None
-    return dict(bound="hbm", kernel="k_colst (fused SumThreshold, all windows in one pass)",
+    traffic, src = _pmc_traffic("sumthreshold", samples)
+    return dict(bound="hbm", kernel="k_colst_mask (fused SumThreshold, all windows in one pass, time axis)",
                 achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
-                traffic_source="profiles/r01_pmc_sumthreshold.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=src,
                 algorithmic_bytes_per_launch=samples * ST_BYTES_PER_SAMPLE,
                 bytes_per_sample=ST_BYTES_PER_SAMPLE, samples_per_launch=samples,
                 ms_per_launch=round(ms.value, 4))
 
 
+def roofline_boxfilter(torch, device, T, F, kw, nwin):
+    """Times the two stages of one masked box filter (flagging.py:469-513) in the step's launch geometry at the
+    radii of the parameter set: the time-axis stage at its largest radius (first background iteration) and the
+    fused frequency-axis stage + masked division at its last radius (the final pass of every background)."""
+    from tricolour_amd import _lib
+    lib = _lib.lib()
+    g = torch.Generator(device=device)
+    g.manual_seed(9)
+    data = torch.randn((nwin, T, F), generator=g, device=device).abs_()
+    wimg = torch.rand((nwin, T, F), generator=g, device=device)
+    f4 = (torch.rand((nwin, T // 4, F), generator=g, device=device) < 0.05).to(torch.int32) * 0x01010101
+    ow = torch.empty((nwin, T, F), device=device)
+    oo = torch.empty((nwin, T, F), device=device)
+    ms = C.c_float(0)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    nit = int(kw.get("background_iterations", 1))
+    swt, swf = float(kw.get("spike_width_time", 12.5)), float(kw.get("spike_width_freq", 10.0))
+    cases = [(0, box_radius(max(nit, 1) * swt), "time-axis stage (k_boxt / k_colfilter_lds), first background iteration"),
+             (1, box_radius(swf), "frequency-axis stage fused with the masked division (k_boxf), last background pass")]
+    if nit > 1:
+        cases.insert(1, (1, box_radius(nit * swf), "frequency-axis stage fused with the masked division (k_boxf), first background iteration"))
+    samples = nwin * T * F
+    out = []
+    for stage, rad, what in cases:
+        if rad <= 0:
+            continue
+        src = f4 if stage == 0 else wimg
+        try:
+            for reps in (1, 4):
+                _lib.check(lib.tri_bench_boxfilter(data.data_ptr(), src.data_ptr(), ow.data_ptr(), oo.data_ptr(),
+                                                   nwin, T, F, rad, stage, 0, reps, C.byref(ms), stream))
+        except (NotImplementedError, ValueError) as e:
+            out.append(dict(bound="hbm", kernel="box filter %s, r = %d" % (what, rad), error=str(e)))
+            continue
+        achieved = samples * BOX_BYTES_PER_SAMPLE / (ms.value * 1e-3) / 1e9
+        traffic, tsrc = _pmc_traffic("boxfilter_s%d_r%d" % (stage, rad), samples)
+        out.append(dict(bound="hbm", kernel="box filter %s, r = %d" % (what, rad),
+                        achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=tsrc,
+                        algorithmic_bytes_per_launch=samples * BOX_BYTES_PER_SAMPLE,
+                        bytes_per_sample=BOX_BYTES_PER_SAMPLE, samples_per_launch=samples,
+                        ms_per_launch=round(ms.value, 4)))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------------
+def chain_setup(nbl, F):
+    """Host-side inputs of the cheap strategy steps: 64 antennas, the first `nbl` baselines in
+    (ant2, ant1) order (packing.py:54-56), a static mask hitting 300 channels."""
+    nant = 64
+    a1, a2 = np.triu_indices(nant, 0)
+    ubl = np.stack([np.arange(nbl), a1[:nbl], a2[:nbl]], axis=1)
+    ants = np.random.RandomState(0).uniform(-4000, 4000, size=(nant, 3))
+    cf = np.linspace(0.856e9, 1.712e9, F)
+    cw = np.full(F, cf[1] - cf[0])
+    masks = [cf[np.random.RandomState(1).choice(F, 300, replace=False)][:, None] + 10.0]
+    return dict(ubl=ubl, ant_pos=ants, chan_freq=cf, chan_width=cw, masked_channels=masks)
+
+
+def chain_strategies(kw):
+    return [dict(task="flag_nans_zeros"),
+            dict(task="apply_static_mask", kwargs=dict(accumulation_mode="or", uvrange="")),
+            dict(task="flag_autos"),
+            dict(task="uvcontsub_flagger", kwargs=dict(UVCONTSUB_KW)),
+            dict(task="sum_threshold", kwargs=kw)]
+
+
+def ska_stream(torch, tricolour_amd, device, kw, nbl, ncorr, T, F, slabs, warmup):
+    """Streams `slabs` window slabs (nbl x ncorr windows of T x F each) through two pinned host buffers:
+    stream A copies slab i+1 host->device while stream B flags slab i and stream C copies the flags of slab
+    i-1 back.  Returns (seconds for `slabs` slabs with transfers, seconds for the same slabs device-resident,
+    flagged fraction)."""
+    shape = (nbl, ncorr, T, F)
+    # host side: two pinned (vis, flags, out) buffer sets filled once with synthetic data
+    vis_d, flags_d = synth_slab(torch, nbl, ncorr, T, F, device, 4321)
+    hv = [torch.empty(shape, dtype=torch.complex64).pin_memory() for _ in range(2)]
+    hf = [torch.empty(shape, dtype=torch.bool).pin_memory() for _ in range(2)]
+    ho = [torch.empty(shape, dtype=torch.bool).pin_memory() for _ in range(2)]
+    for k in range(2):
+        hv[k].copy_(vis_d)
+        hf[k].copy_(flags_d)
+    dv = [torch.empty_like(vis_d) for _ in range(2)]
+    df = [torch.empty_like(flags_d) for _ in range(2)]
+    douts = [None, None]
+    s_in, s_k, s_out = torch.cuda.Stream(device), torch.cuda.Stream(device), torch.cuda.Stream(device)
+    ev_in = [torch.cuda.Event() for _ in range(2)]      # slab landed in dv/df[k]
+    ev_k = [torch.cuda.Event() for _ in range(2)]       # kernels of buffer k done (input reusable, output ready)
+    ev_out = [torch.cuda.Event() for _ in range(2)]     # output of buffer k copied back
+
+    def run(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(s_in):
+            dv[0].copy_(hv[0], non_blocking=True)
+            df[0].copy_(hf[0], non_blocking=True)
+            ev_in[0].record(s_in)
+        for i in range(n):
+            k = i & 1
+            if i + 1 < n:
+                with torch.cuda.stream(s_in):
+                    if i >= 1:
+                        s_in.wait_event(ev_k[1 - k])          # kernels that read dv[1-k] are done
+                    dv[1 - k].copy_(hv[1 - k], non_blocking=True)
+                    df[1 - k].copy_(hf[1 - k], non_blocking=True)
+                    ev_in[1 - k].record(s_in)
+            with torch.cuda.stream(s_k):
+                s_k.wait_event(ev_in[k])
+                if i >= 2:
+                    s_k.wait_event(ev_out[k])                  # previous output of this buffer copied back
+                douts[k] = tricolour_amd.sum_threshold_flagger(dv[k], df[k], **kw)
+                douts[k].record_stream(s_out)
+                ev_k[k].record(s_k)
+            with torch.cuda.stream(s_out):
+                s_out.wait_event(ev_k[k])
+                ho[k].copy_(douts[k], non_blocking=True)
+                ev_out[k].record(s_out)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    run(max(warmup, 1))
+    t_stream = run(slabs)
+    # device-resident rate over the same number of slabs
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = None
+    for i in range(slabs):
+        out = tricolour_amd.sum_threshold_flagger(dv[i & 1], df[i & 1], **kw)
+    torch.cuda.synchronize()
+    t_res = time.perf_counter() - t0
+    return t_stream, t_res, float(out.float().mean().item())
+
+
+def scatter_leg(torch, dist, tricolour_amd, device, rank, world, kw, ncorr, T, F, bl_per_rank, backend):
+    """Rank 0 synthesises world x bl_per_rank baselines, fans the slabs out with batched point-to-point
+    sends (RCCL: each peer's slab rides its own xGMI link), every rank flags its slab, the uint8 flags are
+    gathered back.  Separately timed; never part of `value`."""
+    from tricolour_amd import distributed as D
+    nbl = world * bl_per_rank
+    shape = (nbl, ncorr, T, F)
+    comm_dev = device if backend == "nccl" else torch.device("cpu")
+    vis = flags = None
+    if rank == 0:
+        vis, flags = synth_slab(torch, nbl, ncorr, T, F, device, 99)
+        if backend != "nccl":
+            vis, flags = vis.cpu(), flags.cpu()
+
+    def sync():
+        torch.cuda.synchronize()
+        dist.barrier()
+
+    sync()
+    t0 = time.perf_counter()
+    v, f = D.scatter_windows(vis, flags, shape, src=0, device=comm_dev)
+    sync()
+    t1 = time.perf_counter()
+    out = tricolour_amd.sum_threshold_flagger(v.to(device), f.to(device), **kw)
+    sync()
+    t2 = time.perf_counter()
+    full = D.gather_flags(out if backend == "nccl" else out.cpu(), shape, dst=0)
+    sync()
+    t3 = time.perf_counter()
+    # every rank's flag count must arrive at the root unchanged
+    cnt = torch.tensor([float(out.sum().item())], dtype=torch.float64, device=comm_dev)
+    dist.all_reduce(cnt)
+    res = None
+    if rank == 0:
+        sent = (nbl - bl_per_rank) * ncorr * T * F      # samples that left / re-entered the root
+        ok = abs(float(full.sum().item()) - float(cnt.item())) < 0.5
+        res = dict(backend="rccl" if backend == "nccl" else backend, baselines_per_rank=bl_per_rank,
+                   scatter_gb_s=round(sent * 9 / (t1 - t0) / 1e9, 2), gather_gb_s=round(sent / (t3 - t2) / 1e9, 2),
+                   scatter_s=round(t1 - t0, 4), flag_s=round(t2 - t1, 4), gather_s=round(t3 - t2, 4),
+                   flag_count_matches=bool(ok))
+    del vis, flags, v, f, out, full
+    return res
+
+
+def self_launch(args):
+    """`bench.py --gpus N` outside a torchrun environment: start the N ranks as child processes (before any
+    GPU call in this process) and relay rank 0's line."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["TRI_BENCH_CHILD"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, env=env)
+    sys.exit(p.returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--bl", type=int, default=int(os.environ.get("TRI_BENCH_BL", "252")),
-                    help="baselines per rank (slab of the 2016-baseline configuration)")
-    ap.add_argument("--corr", type=int, default=4)
-    ap.add_argument("--time", type=int, default=1024)
-    ap.add_argument("--chan", type=int, default=4096)
-    ap.add_argument("--params", choices=sorted(PARAM_SETS), default="defaults")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=["slab", "chain", "ska"], default="slab")
+    ap.add_argument("--bl", type=int, default=None,
+                    help="baselines per rank (slab: 252 of the 2016-baseline configuration; chain: 84 per scan; "
+                         "ska: 32 per streamed slab)")
+    ap.add_argument("--corr", type=int, default=None)
+    ap.add_argument("--time", type=int, default=None)
+    ap.add_argument("--chan", type=int, default=None)
+    ap.add_argument("--scans", type=int, default=3, help="chain: scans per step")
+    ap.add_argument("--params", choices=sorted(PARAM_SETS), default=None)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                          "several ranks on one GPU)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal: map every rank to cuda:0 (with --backend gloo)")
+    ap.add_argument("--scatter-bl", type=int, default=8, help="baselines per rank in the N > 1 scatter / gather leg")
+    ap.add_argument("--no-scatter", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-other-params", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher rehearsal without a GPU: every rank joins a gloo group, rank 0 prints the rank count")
     args = ap.parse_args()
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        self_launch(args)                      # never returns
+    world = int(env_world or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with `python bench.py --gpus N` (self-launching) or "
+                  "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+
+    if args.dry_run:
+        import torch
+        import torch.distributed as dist
+        n = 1
+        if world > 1:
+            dist.init_process_group("gloo")
+            t = torch.ones(1)
+            dist.all_reduce(t)
+            n = int(t.item())
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_joined": n}))
+        return
+
+    wl = args.workload
+    ncorr = args.corr or (2 if wl == "ska" else 4)
+    T = args.time or (512 if wl == "ska" else 1024)
+    F = args.chan or (65536 if wl == "ska" else 4096)
+    nbl = args.bl or int(os.environ.get("TRI_BENCH_BL", {"slab": "252", "chain": "84", "ska": "32"}[wl]))
+    pname = args.params or ("defaults" if wl == "ska" else "stage1")
+    steps = args.steps if args.steps is not None else {"slab": 2, "chain": 1, "ska": 64}[wl]
+    warmup = args.warmup if args.warmup is not None else {"slab": 1, "chain": 1, "ska": 2}[wl]
+    kw = PARAM_SETS[pname]
 
     import torch
     from tricolour_amd import _lib
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and _lib.needs_build():
+    if world == 1 and _lib.needs_build():
         _lib.build()          # in-tree hipcc build (normally done by __graft_entry__.build())
     import tricolour_amd
     from tricolour_amd import flagging
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -207,13 +479,6 @@ def main():
     else:
         torch.cuda.set_device(0)
     device = torch.device("cuda", torch.cuda.current_device())
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
-
-    kw = PARAM_SETS[args.params]
-    T, F = args.time, args.chan
-    vis, flags = synth_slab(torch, args.bl, args.corr, T, F, device, 1234 + rank)
-    torch.cuda.synchronize()
 
     def barrier():
         torch.cuda.synchronize()
@@ -221,58 +486,126 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    extra = {}
+    nvis_step = nbl * ncorr * T * F
+    if wl == "slab":
+        vis, flags = synth_slab(torch, nbl, ncorr, T, F, device, 1234 + rank)
+        step = lambda: tricolour_amd.sum_threshold_flagger(vis, flags, **kw)
+        workload = ("MeerKAT-64 slab: %d of 2016 bl x %d corr x %d time x %d chan per GPU (BASELINE configs[1] "
+                    "processed as HBM-resident baseline slabs), sum_threshold_flagger kwargs=%s" % (nbl, ncorr, T, F, pname)) \
+            if (ncorr, T, F) == (4, 1024, 4096) else \
+            ("custom window set: %d bl x %d corr x %d time x %d chan per GPU, sum_threshold_flagger kwargs=%s"
+             % (nbl, ncorr, T, F, pname))
+    elif wl == "chain":
+        from tricolour_amd.strategies import apply_strategies
+        scans = [synth_slab(torch, nbl, ncorr, T, F, device, 1234 + 17 * s + rank) for s in range(args.scans)]
+        setup = chain_setup(nbl, F)
+        strategies = chain_strategies(kw)
+
+        def step():
+            out = None
+            for v, f in scans:
+                out = apply_strategies(strategies, f, v, **setup)
+            return out
+        nvis_step *= args.scans
+        workload = ("multi-scan chain (BASELINE configs[3]): %d scans x (%d bl x %d corr x %d time x %d chan) per GPU, "
+                    "each flag_nans_zeros -> apply_static_mask(or) -> flag_autos -> uvcontsub_flagger -> sum_threshold "
+                    "(kwargs=%s), device-resident" % (args.scans, nbl, ncorr, T, F, pname))
+    else:
+        workload = ("SKA-Mid window geometry (BASELINE configs[4]): slabs of %d bl x %d corr x %d time x %d chan "
+                    "per GPU, sum_threshold_flagger kwargs=%s; value = device-resident rate over %d slabs"
+                    % (nbl, ncorr, T, F, pname, steps))
+    torch.cuda.synchronize()
+
     out = None
-    for _ in range(args.warmup):
-        out = tricolour_amd.sum_threshold_flagger(vis, flags, **kw)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = tricolour_amd.sum_threshold_flagger(vis, flags, **kw)
-    barrier()
-    dt = time.perf_counter() - t0
+    if wl == "ska":
+        barrier()
+        t_stream, dt, flagged = ska_stream(torch, tricolour_amd, device, kw, nbl, ncorr, T, F, steps, warmup)
+        barrier()
+        extra["pcie_inclusive"] = dict(value=round(nvis_step * steps * world / t_stream / 1e6, 2), unit="Mvis/s",
+                                       what="same slabs streamed host->device->host through two pinned buffers, "
+                                            "H2D / kernels / D2H overlapped on three streams (10 B/vis over PCIe)",
+                                       seconds=round(t_stream, 3))
+    else:
+        for _ in range(warmup):
+            out = step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        barrier()
+        dt = time.perf_counter() - t0
+        flagged = float(out.float().mean().item()) if out is not None else float("nan")
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    flagged = float(out.float().mean().item()) if out is not None else float("nan")
-    nvis_rank = args.bl * args.corr * T * F
-    total_vis = nvis_rank * world * args.steps
+    total_vis = nvis_step * world * steps
     value = total_vis / dt / 1e6
 
+    res = None
     if rank == 0:
         res = {
             "metric": "Mvis/s flagged (bl x time x chan x corr)",
             "value": round(value, 2),
             "unit": "Mvis/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3),
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": round(dt / max(steps, 1) * 1e3, 3),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32 data / f64 accumulators / u8 flags",
             "data": "synthetic",
             "config": {
-                "workload": ("MeerKAT-64 slab: %d of 2016 bl x %d corr x %d time x %d chan per GPU "
-                             "(BASELINE configs[1] processed as HBM-resident baseline slabs), "
-                             "sum_threshold_flagger kwargs=%s" % (args.bl, args.corr, T, F, args.params))
-                if (args.corr, T, F) == (4, 1024, 4096) else
-                ("custom window set: %d bl x %d corr x %d time x %d chan per GPU, "
-                 "sum_threshold_flagger kwargs=%s" % (args.bl, args.corr, T, F, args.params)),
-                "baselines_per_gpu": args.bl,
-                "params": args.params,
+                "workload": workload,
+                "baselines_per_gpu": nbl,
+                "params": pname,
                 "sharding": "baselines across ranks, no data-path collective",
                 "flagged_fraction": round(flagged, 4),
             },
         }
-        del vis, flags, out
+        res.update(extra)
+    # the same slab under the other shipped parameter sets (extra keys, N = 1, slab workload)
+    if wl == "slab" and world == 1 and not args.no_other_params:
+        others = {}
+        for other in sorted(PARAM_SETS):
+            if other == pname:
+                continue
+            okw = PARAM_SETS[other]
+            tricolour_amd.sum_threshold_flagger(vis, flags, **okw)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                tricolour_amd.sum_threshold_flagger(vis, flags, **okw)
+            torch.cuda.synchronize()
+            odt = (time.perf_counter() - t0) / 2
+            others[other] = dict(value=round(nvis_step / odt / 1e6, 2), unit="Mvis/s", ms_per_step=round(odt * 1e3, 3), steps=2)
+        res["other_params"] = others
+    if wl == "slab":
+        del vis, flags
+    elif wl == "chain":
+        del scans
+    out = None
+    flagging.release_workspace()
+    torch.cuda.empty_cache()
+    if dist is not None and not args.no_scatter:
+        try:
+            sc = scatter_leg(torch, dist, tricolour_amd, device, rank, world, kw, ncorr, T, F, args.scatter_bl, args.backend)
+        except Exception as e:        # the headline line must survive a failing rehearsal leg
+            sc = dict(error="%s: %s" % (type(e).__name__, e))
+        if rank == 0:
+            res["scatter"] = sc
         flagging.release_workspace()
         torch.cuda.empty_cache()
+    if rank == 0:
+        nwin = min(nbl * ncorr, 1008 if wl != "ska" else 16)
         if not args.no_roofline:
-            res["roofline"] = roofline_sumthreshold(torch, device, T, F, kw, min(args.bl * args.corr, 1008))
+            res["roofline"] = [roofline_sumthreshold(torch, device, T, F, kw, nwin)] + \
+                roofline_boxfilter(torch, device, T, F, kw, nwin)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(kw, T, F)
+            res["cpu_baseline"] = cpu_baseline(kw, T, F, chain=UVCONTSUB_KW if wl == "chain" else None)
         print(json.dumps(res))
         sys.stdout.flush()
     if dist is not None:
