@@ -208,7 +208,10 @@ def _np_median_abs(vals):
     (2, 4096, [0, 4, 8, 2048, 4096], (2, 3)),
     (1, 6000, [0, 1, 2, 3001, 6000], (2,)),
     (4, 64, [0, 0, 1, 2, 64], (1, 2)),
-    (1, 300000, [0, 100000, 300000], (2, 3)),
+    (1, 300000, [0, 100000, 300000], (2, 3, 5, 6)),
+    (2, 4096, [0, 4, 8, 2048, 4096], (5, 6)),
+    (3, 40000, [0, 4000, 4004, 40000], (5, 6)),
+    (1, 6000, [0, 1, 2, 3001, 6000], (6,)),
 ])
 def test_median_kernels(gpu, rows, row_len, ends, variants):
     import ctypes as C

@@ -16,6 +16,16 @@
 // grid (R*G, W), block 256
 // ---------------------------------------------------------------------------
 #define SEL_CACHE 8
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor(v, o, 64));
+    return v;
+}
 #define SEL_BINS 2048
 // Three radix passes over the 31-bit key: digits of 11, 10 and 10 bits.  The
 // even-count partner (rank n/2 - 1) needs no extra pass: it equals the median
@@ -162,6 +172,308 @@ k_median(const float* __restrict__ data, const uint8_t* __restrict__ flags,
 }
 
 // ---------------------------------------------------------------------------
+// K3c  Two-pass form of k_median for long contiguous segments (the per-chunk block
+// medians of _median_abs, flagging.py:267-279: T x chunk samples).  k_median reads the
+// segment three times (11 + 10 + 10 key bits) and its first digit is the float's exponent
+// plus three mantissa bits, so a handful of LDS bins take every atomic.  Here
+//   pass 0  looks at 2048 evenly spaced samples and takes their key range [lo, hi];
+//   pass 1  histograms ALL unflagged keys into 2048 bins through the monotone map
+//           bin(k) = k < lo ? 0 : min(2047, 1 + ((k - lo) >> S))   (S from the range):
+//           bins are ~1/200 of an octave wide where the samples are, so atomics spread
+//           and the bin holding rank n/2 has ~N/400 keys;
+//   pass 2  re-reads the segment (L2 / Infinity Cache resident: <= a few MB), compacts that
+//           bin's keys into LDS and remembers the largest key of the lower bins;
+//   then the exact 3-digit radix select of k_median runs on the LDS candidates.
+// Any monotone map selects exactly; the sample only decides how well the bins resolve.
+// If the rank falls into a catch-all end bin or the bin overflows the LDS list, the
+// workgroup runs the three-pass select on the whole segment instead.
+// grid (R*G, W), block 256; VEC as k_median
+// ---------------------------------------------------------------------------
+#define SEL2_CAND 4096
+#ifndef MED2_UNROLL
+#define MED2_UNROLL 4          // 16-byte groups in flight per thread
+#endif
+struct Sel3State {
+    unsigned n, hi, lo;
+    bool lo_found;      // false: rank kk - 1 lies outside the visited set
+};
+
+// The three-digit exact select of k_median over the keys a thread-level enumerator hands to
+// `visit` (called by all 256 threads; barriers inside).  rank < 0: select rank n / 2 of the
+// visited keys; else that rank.  hist: 2048 words; sh: 9 words of scratch.
+template <typename ENUM>
+__device__ __forceinline__ Sel3State select3(unsigned* hist, unsigned* sh, ENUM&& enumerate, long long rank) {
+    unsigned* sh_wsum = sh;          // [4]
+    unsigned& sh_prefix = sh[4];
+    unsigned& sh_k = sh[5];
+    unsigned& sh_sel = sh[6];
+    unsigned& sh_maxbelow1 = sh[7];  // largest key with a smaller 21-bit prefix, + 1 (0: none)
+    unsigned& sh_lobin1 = sh[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { sh_maxbelow1 = 0; sh_lobin1 = 0; }
+    unsigned prefix = 0, pmask = 0, kk = 0, n = 0;
+    for (int p = 0; p < 3; p++) {
+        const int shift = p == 0 ? 20 : (p == 1 ? 10 : 0);
+        const unsigned dm = p == 0 ? 0x7FFu : 0x3FFu;
+#pragma unroll
+        for (int u = 0; u < SEL_BINS / 256; u++) hist[u * 256 + tid] = 0;
+        __syncthreads();
+        unsigned mb1 = 0;
+        enumerate([&](unsigned k) {
+            if ((k & pmask) == prefix) atomicAdd(&hist[(k >> shift) & dm], 1u);
+            else if (p == 2 && k < prefix) mb1 = max(mb1, k + 1);
+        });
+        if (p == 2 && mb1) atomicMax(&sh_maxbelow1, mb1);
+        __syncthreads();
+        unsigned v[8];
+        {
+            uint4 q0 = reinterpret_cast<const uint4*>(hist)[2 * tid];
+            uint4 q1 = reinterpret_cast<const uint4*>(hist)[2 * tid + 1];
+            v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w;
+            v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+        }
+        unsigned sacc = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) sacc += v[j];
+        unsigned inc = sacc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            unsigned t2 = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t2;
+        }
+        if (lane == 63) sh_wsum[wave] = inc;
+        __syncthreads();
+        unsigned woff = 0, total = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; w2++) {
+            unsigned t2 = sh_wsum[w2];
+            if (w2 < wave) woff += t2;
+            total += t2;
+        }
+        if (p == 0) { n = total; kk = rank < 0 ? (total >> 1) : (unsigned)rank; }
+        unsigned exc = woff + inc - sacc;
+        if (total > 0 && kk >= exc && kk < exc + sacc) {
+            unsigned c = exc;
+            int j = 0;
+#pragma unroll
+            for (int q = 0; q < 7; q++)
+                if (j == q && kk >= c + v[q]) { c += v[q]; j = q + 1; }
+            sh_sel = 8u * tid + j;
+            sh_prefix = prefix | ((8u * tid + j) << shift);
+            sh_k = kk - c;
+        }
+        __syncthreads();
+        if (n == 0) break;
+        if (p == 2) {
+            unsigned sel = sh_sel, cand = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (v[j] && 8u * tid + j < sel) cand = 8u * tid + j + 1;
+            if (cand) atomicMax(&sh_lobin1, cand);
+        }
+        prefix = sh_prefix;
+        kk = sh_k;
+        pmask |= dm << shift;
+        __syncthreads();
+    }
+    Sel3State st;
+    st.n = n;
+    st.hi = prefix;
+    st.lo_found = true;
+    if (kk > 0) st.lo = prefix;                                        // the selected key is duplicated below its rank
+    else if (sh_lobin1) st.lo = (prefix & ~0x3FFu) | (sh_lobin1 - 1);
+    else if (sh_maxbelow1) st.lo = sh_maxbelow1 - 1;
+    else { st.lo = 0; st.lo_found = false; }
+    return st;
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+k_median2(const float* __restrict__ data, const uint8_t* __restrict__ flags,
+          double* __restrict__ med, size_t WSd, size_t WSf, size_t RS, size_t ES,
+          const int64_t* __restrict__ seg_start, const int64_t* __restrict__ seg_len,
+          int R, int G) {
+    __shared__ unsigned hist[SEL_BINS];
+    __shared__ unsigned cand[SEL2_CAND];
+    __shared__ unsigned sh[9];
+    __shared__ unsigned sh_lo, sh_hi, sh_bin, sh_exc, sh_ncand, sh_below1, sh_mode;
+    const int seg = blockIdx.x;
+    const int row = seg / G, g = seg % G;
+    const size_t win = blockIdx.y;
+    const int64_t len = seg_len[g];
+    const size_t rel = (size_t)row * RS + (size_t)seg_start[g] * ES;
+    data += win * WSd + rel;
+    flags += win * WSf + rel;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // every unflagged key of the segment, in this thread's share
+    auto enumerate_all = [&](auto&& visit) {
+        if (VEC) {
+            const float4* d4 = reinterpret_cast<const float4*>(data);
+            const uchar4* f4 = reinterpret_cast<const uchar4*>(flags);
+            const int64_t n4 = len / 4;
+            // MED2_UNROLL 16-byte groups in flight per thread: the segment streams from HBM once
+            // (pass 1) and from L2 / Infinity Cache afterwards
+            int64_t i = tid;
+            for (; i + 256 * (MED2_UNROLL - 1) < n4; i += 256 * MED2_UNROLL) {
+                float4 dv[MED2_UNROLL];
+                uchar4 fv[MED2_UNROLL];
+#pragma unroll
+                for (int q = 0; q < MED2_UNROLL; q++) { dv[q] = d4[i + 256 * q]; fv[q] = f4[i + 256 * q]; }
+#pragma unroll
+                for (int q = 0; q < MED2_UNROLL; q++) {
+                    if (!fv[q].x) visit(__float_as_uint(dv[q].x) & 0x7FFFFFFFu);
+                    if (!fv[q].y) visit(__float_as_uint(dv[q].y) & 0x7FFFFFFFu);
+                    if (!fv[q].z) visit(__float_as_uint(dv[q].z) & 0x7FFFFFFFu);
+                    if (!fv[q].w) visit(__float_as_uint(dv[q].w) & 0x7FFFFFFFu);
+                }
+            }
+            for (; i < n4; i += 256) {
+                float4 dv = d4[i];
+                uchar4 fv = f4[i];
+                if (!fv.x) visit(__float_as_uint(dv.x) & 0x7FFFFFFFu);
+                if (!fv.y) visit(__float_as_uint(dv.y) & 0x7FFFFFFFu);
+                if (!fv.z) visit(__float_as_uint(dv.z) & 0x7FFFFFFFu);
+                if (!fv.w) visit(__float_as_uint(dv.w) & 0x7FFFFFFFu);
+            }
+        } else {
+            for (int64_t i = tid; i < len; i += 256) {
+                size_t a = (size_t)i * ES;
+                if (!flags[a]) visit(__float_as_uint(data[a]) & 0x7FFFFFFFu);
+            }
+        }
+    };
+    auto finish = [&](const Sel3State& st, unsigned below1) {
+        if (tid != 0) return;
+        const size_t oidx = (win * (size_t)R + row) * G + g;
+        double m;
+        if (st.n == 0) m = __longlong_as_double(0x7FF8000000000000LL);
+        else if (st.n & 1u) m = (double)__uint_as_float(st.hi);
+        else {
+            const unsigned lo = st.lo_found ? st.lo : below1 - 1;
+            float sm = __uint_as_float(lo) + __uint_as_float(st.hi);
+            m = (double)sm / 2.0;
+        }
+        med[oidx] = m;
+    };
+
+    // ---- pass 0: key range of 2048 evenly spaced samples ----
+    if (tid == 0) { sh_lo = 0xFFFFFFFFu; sh_hi = 0; sh_ncand = 0; sh_below1 = 0; sh_mode = 0; }
+    __syncthreads();
+    {
+        unsigned kmin = 0xFFFFFFFFu, kmax = 0;
+        const int64_t stride = len / 2048 > 0 ? len / 2048 : 1;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int64_t i = (int64_t)(j * 256 + tid) * stride;
+            if (i < len) {
+                const size_t a = (size_t)i * ES;
+                if (!flags[a]) {
+                    const unsigned k = __float_as_uint(data[a]) & 0x7FFFFFFFu;
+                    kmin = min(kmin, k);
+                    kmax = max(kmax, k);
+                }
+            }
+        }
+        kmin = ~wave_max_u32(~kmin);
+        kmax = wave_max_u32(kmax);
+        if (lane == 0) { atomicMin(&sh_lo, kmin); atomicMax(&sh_hi, kmax); }
+    }
+    __syncthreads();
+    const unsigned lo = sh_lo, hi = sh_hi;
+    // bins 1..2046 cover [lo, lo + 2046 << S); no sample unflagged: one catch-all -> fallback below
+    int S = 0;
+    if (hi >= lo) {
+        const unsigned span = hi - lo;
+        while (S < 31 && (span >> S) >= 2046u) S++;
+    }
+    auto bin_of = [&](unsigned k) -> unsigned {
+        if (k < lo) return 0u;
+        const unsigned b = ((k - lo) >> S) + 1u;
+        return b > 2047u ? 2047u : b;
+    };
+
+    // ---- pass 1: histogram of every unflagged key ----
+#pragma unroll
+    for (int u = 0; u < SEL_BINS / 256; u++) hist[u * 256 + tid] = 0;
+    __syncthreads();
+    if (hi >= lo) enumerate_all([&](unsigned k) { atomicAdd(&hist[bin_of(k)], 1u); });
+    __syncthreads();
+    if (hi >= lo) {
+        unsigned v[8];
+        uint4 q0 = reinterpret_cast<const uint4*>(hist)[2 * tid];
+        uint4 q1 = reinterpret_cast<const uint4*>(hist)[2 * tid + 1];
+        v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w;
+        v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+        unsigned sacc = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) sacc += v[j];
+        unsigned inc = sacc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            unsigned t2 = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t2;
+        }
+        if (lane == 63) sh[wave] = inc;
+        __syncthreads();
+        unsigned woff = 0, total = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; w2++) {
+            unsigned t2 = sh[w2];
+            if (w2 < wave) woff += t2;
+            total += t2;
+        }
+        const unsigned kk = total >> 1;
+        const unsigned exc = woff + inc - sacc;
+        if (total > 0 && kk >= exc && kk < exc + sacc) {
+            unsigned c = exc;
+            int j = 0;
+#pragma unroll
+            for (int q = 0; q < 7; q++)
+                if (j == q && kk >= c + v[q]) { c += v[q]; j = q + 1; }
+            const unsigned b = 8u * tid + j;
+            sh_bin = b;
+            sh_exc = c;
+            // usable: an interior bin whose keys fit the LDS list
+            sh_mode = (b >= 1 && b <= 2046 && v[j] <= SEL2_CAND) ? 1u : 0u;
+        }
+        __syncthreads();
+    }
+    if (sh_mode == 0) {
+        // nothing sampled, empty segment, end bin or overfull bin: three passes over the segment
+        const Sel3State st = select3(hist, sh, enumerate_all, -1);
+        finish(st, 1);
+        return;
+    }
+    const unsigned bsel = sh_bin, exc = sh_exc;
+    unsigned total = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < 4; w2++) total += sh[w2];
+    __syncthreads();   // sh[] is reused by select3 below
+
+    // ---- pass 2: compact the selected bin's keys, largest key of the lower bins ----
+    {
+        unsigned mb1 = 0;
+        enumerate_all([&](unsigned k) {
+            const unsigned b = bin_of(k);
+            if (b == bsel) cand[atomicAdd(&sh_ncand, 1u)] = k;
+            else if (b < bsel) mb1 = max(mb1, k + 1);
+        });
+        mb1 = wave_max_u32(mb1);
+        if (lane == 0 && mb1) atomicMax(&sh_below1, mb1);
+    }
+    __syncthreads();
+    const unsigned ncand = sh_ncand, below1 = sh_below1;
+    // ---- exact select of rank (n/2 - exc) among the candidates ----
+    auto enumerate_cand = [&](auto&& visit) {
+        for (unsigned i = tid; i < ncand; i += 256) visit(cand[i]);
+    };
+    Sel3State st = select3(hist, sh, enumerate_cand, (long long)((total >> 1) - exc));
+    st.n = total;
+    finish(st, below1);
+}
+
+// ---------------------------------------------------------------------------
 // K3b  Wave-per-segment form of k_median for segments of at most 1024 samples
 // (time lines of a window, per-chunk channel runs): the segment's keys stay in
 // registers (16 per lane), each wave owns a 256-bin LDS histogram, and the
@@ -170,16 +482,6 @@ k_median(const float* __restrict__ data, const uint8_t* __restrict__ flags,
 // grid (ceil(R*G/4), W), block 256
 // ---------------------------------------------------------------------------
 #define MW_K 16   // register slots per lane of the largest instantiation (segments <= 1024)
-__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor(v, o, 64));
-    return v;
-}
 
 template <int KS, bool VEC4>   // KS register slots per lane: segments of at most 64 * KS samples
 __global__ void __launch_bounds__(256)

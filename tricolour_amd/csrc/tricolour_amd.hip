@@ -375,12 +375,19 @@ int launch_median(const Run& r, const float* data, const uint8_t* flags, double*
     else if (max_len <= 64 * MW_K)
         hipLaunchKernelGGL((k_median_wave<MW_K, false>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)W), dim3(256), 0, r.st,
                            data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
-    else if (vec_ok)
-        hipLaunchKernelGGL(k_median<true>, dim3((unsigned)(R * G), (unsigned)W), dim3(256), 0, r.st, data,
-                           flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
-    else
-        hipLaunchKernelGGL(k_median<false>, dim3((unsigned)(R * G), (unsigned)W), dim3(256), 0, r.st, data,
-                           flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
+    else {
+        // long segments: two-pass select (K3c); TRI_MEDIAN_3PASS=1 keeps the three-pass kernel (A/B runs, tests)
+        static const bool three = [] { const char* e = getenv("TRI_MEDIAN_3PASS"); return e && e[0] == '1'; }();
+        const dim3 grid((unsigned)(R * G), (unsigned)W);
+        if (three && vec_ok)
+            hipLaunchKernelGGL(k_median<true>, grid, dim3(256), 0, r.st, data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
+        else if (three)
+            hipLaunchKernelGGL(k_median<false>, grid, dim3(256), 0, r.st, data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
+        else if (vec_ok)
+            hipLaunchKernelGGL(k_median2<true>, grid, dim3(256), 0, r.st, data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
+        else
+            hipLaunchKernelGGL(k_median2<false>, grid, dim3(256), 0, r.st, data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
+    }
     LAUNCHCHK();
     return TRI_OK;
 }
@@ -1447,7 +1454,7 @@ extern "C" int tri_test_median(const float* data, const uint8_t* flags, double* 
     if (variant == 0) variant = maxlen <= 64 * MW_K ? 1 : (al4 ? 3 : 2);
     if ((variant == 1 || variant == 4) && maxlen > 64 * MW_K) return set_err(TRI_EINVAL, "wave kernel handles segments <= 1024");
     if (variant == 4 && (row_len % 4 != 0 || maxlen + 3 > 64 * MW_K)) return set_err(TRI_EINVAL, "masked vector variant needs row_len % 4 == 0 and segments <= 1021");
-    if (variant == 3 && !al4) return set_err(TRI_EINVAL, "vector loads need 4-aligned segments");
+    if ((variant == 3 || variant == 5) && !al4) return set_err(TRI_EINVAL, "vector loads need 4-aligned segments");
     if (variant == 1 && maxlen <= 64 * 8)
         hipLaunchKernelGGL((k_median_wave<8, false>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)n_win), dim3(256), 0, st,
                            data, flags, med, WS, WS, RS, (size_t)1, d_start, d_len, R, G);
@@ -1463,6 +1470,12 @@ extern "C" int tri_test_median(const float* data, const uint8_t* flags, double* 
                            data, flags, med, WS, WS, RS, (size_t)1, d_start, d_len, R, G);
     else if (variant == 3)
         hipLaunchKernelGGL(k_median<true>, dim3((unsigned)(R * G), (unsigned)n_win), dim3(256), 0, st, data, flags,
+                           med, WS, WS, RS, (size_t)1, d_start, d_len, R, G);
+    else if (variant == 5)
+        hipLaunchKernelGGL(k_median2<true>, dim3((unsigned)(R * G), (unsigned)n_win), dim3(256), 0, st, data, flags,
+                           med, WS, WS, RS, (size_t)1, d_start, d_len, R, G);
+    else if (variant == 6)
+        hipLaunchKernelGGL(k_median2<false>, dim3((unsigned)(R * G), (unsigned)n_win), dim3(256), 0, st, data, flags,
                            med, WS, WS, RS, (size_t)1, d_start, d_len, R, G);
     else
         hipLaunchKernelGGL(k_median<false>, dim3((unsigned)(R * G), (unsigned)n_win), dim3(256), 0, st, data, flags,
@@ -1627,14 +1640,14 @@ extern "C" int tri_uvcontsub_flagger(const void* vis_c64, const uint8_t* flags, 
             LAUNCHCHK();
             // nanmedian over the unflagged, non-NaN residuals of each product (:1061)
             if (vec)
-                hipLaunchKernelGGL(k_median<true>, dim3(1, (unsigned)B), dim3(256), 0, st, absres, mflags, med1, N, N, (size_t)0, (size_t)1, seg, seg + 1, 1, 1);
+                hipLaunchKernelGGL(k_median2<true>, dim3(1, (unsigned)B), dim3(256), 0, st, absres, mflags, med1, N, N, (size_t)0, (size_t)1, seg, seg + 1, 1, 1);
             else
-                hipLaunchKernelGGL(k_median<false>, dim3(1, (unsigned)B), dim3(256), 0, st, absres, mflags, med1, N, N, (size_t)0, (size_t)1, seg, seg + 1, 1, 1);
+                hipLaunchKernelGGL(k_median2<false>, dim3(1, (unsigned)B), dim3(256), 0, st, absres, mflags, med1, N, N, (size_t)0, (size_t)1, seg, seg + 1, 1, 1);
             hipLaunchKernelGGL(k_uv_diff, dim3((unsigned)cdiv((int64_t)N, 256), (unsigned)B), dim3(256), 0, st, absres, med1, diff, N);
             if (vec)
-                hipLaunchKernelGGL(k_median<true>, dim3(1, (unsigned)B), dim3(256), 0, st, diff, mflags, mad, N, N, (size_t)0, (size_t)1, seg, seg + 1, 1, 1);
+                hipLaunchKernelGGL(k_median2<true>, dim3(1, (unsigned)B), dim3(256), 0, st, diff, mflags, mad, N, N, (size_t)0, (size_t)1, seg, seg + 1, 1, 1);
             else
-                hipLaunchKernelGGL(k_median<false>, dim3(1, (unsigned)B), dim3(256), 0, st, diff, mflags, mad, N, N, (size_t)0, (size_t)1, seg, seg + 1, 1, 1);
+                hipLaunchKernelGGL(k_median2<false>, dim3(1, (unsigned)B), dim3(256), 0, st, diff, mflags, mad, N, N, (size_t)0, (size_t)1, seg, seg + 1, 1, 1);
             hipLaunchKernelGGL(k_uv_apply, dim3((unsigned)cdiv((int64_t)N, 256), (unsigned)B), dim3(256), 0, st, absres, mad, cnt, rf, (float)sigma, mi >= or_original_from_cycle ? 1 : 0, N);
             LAUNCHCHK();
         }
