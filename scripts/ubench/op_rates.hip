@@ -1,0 +1,86 @@
+// Issue-rate microbenchmark for the instructions of the box-filter cascade (gfx950).
+// hipcc --offload-arch=gfx950 -O3 -o op_rates op_rates.hip && ./op_rates
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#define N_IT 4096
+template <int OP>
+__global__ void k(double* out, float seed, int waves_note) {
+    double a0 = seed, a1 = seed + 1, a2 = seed + 2, a3 = seed + 3, a4 = seed + 4, a5 = seed + 5, a6 = seed + 6, a7 = seed + 7;
+    float f0 = seed, f1 = seed + 1, f2 = seed + 2, f3 = seed + 3, f4 = seed + 4, f5 = seed + 5, f6 = seed + 6, f7 = seed + 7;
+    long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < N_IT; i++) {
+        if (OP == 0) {  // v_add_f64, 8 independent chains
+            asm volatile("v_add_f64 %0, %0, %8\n v_add_f64 %1, %1, %8\n v_add_f64 %2, %2, %8\n v_add_f64 %3, %3, %8\n"
+                         "v_add_f64 %4, %4, %8\n v_add_f64 %5, %5, %8\n v_add_f64 %6, %6, %8\n v_add_f64 %7, %7, %8\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(1.5));
+        } else if (OP == 1) {  // v_cvt_f64_f32
+            asm volatile("v_cvt_f64_f32 %0, %8\n v_cvt_f64_f32 %1, %9\n v_cvt_f64_f32 %2, %10\n v_cvt_f64_f32 %3, %11\n"
+                         "v_cvt_f64_f32 %4, %12\n v_cvt_f64_f32 %5, %13\n v_cvt_f64_f32 %6, %14\n v_cvt_f64_f32 %7, %15\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                         : "v"(f0), "v"(f1), "v"(f2), "v"(f3), "v"(f4), "v"(f5), "v"(f6), "v"(f7));
+        } else if (OP == 2) {  // v_cvt_f32_f64
+            asm volatile("v_cvt_f32_f64 %0, %8\n v_cvt_f32_f64 %1, %9\n v_cvt_f32_f64 %2, %10\n v_cvt_f32_f64 %3, %11\n"
+                         "v_cvt_f32_f64 %4, %12\n v_cvt_f32_f64 %5, %13\n v_cvt_f32_f64 %6, %14\n v_cvt_f32_f64 %7, %15\n"
+                         : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7)
+                         : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7));
+        } else if (OP == 3) {  // v_add_f32
+            asm volatile("v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n"
+                         "v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_add_f32 %6, %6, %8\n v_add_f32 %7, %7, %8\n"
+                         : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7) : "v"(1.5f));
+        } else if (OP == 4) {  // dependent v_add_f64 chain (latency)
+            asm volatile("v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n"
+                         "v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n"
+                         : "+v"(a0) : "v"(1.5));
+        } else if (OP == 5) {  // the cascade's dependent chain: add, cvt to f32, cvt back, add (one stage per step)
+            asm volatile("v_add_f64 %0, %0, %2\n v_cvt_f32_f64 %1, %0\n v_add_f64 %0, %0, %3\n v_cvt_f64_f32 %2, %1\n"
+                         "v_add_f64 %0, %0, %2\n v_cvt_f32_f64 %1, %0\n v_add_f64 %0, %0, %3\n v_cvt_f64_f32 %2, %1\n"
+                         : "+v"(a0), "+v"(f0), "+v"(a1) : "v"(a2));
+        } else if (OP == 6) {  // v_fma_f32 (division helper class)
+            asm volatile("v_fma_f32 %0, %0, %8, %8\n v_fma_f32 %1, %1, %8, %8\n v_fma_f32 %2, %2, %8, %8\n v_fma_f32 %3, %3, %8, %8\n"
+                         "v_fma_f32 %4, %4, %8, %8\n v_fma_f32 %5, %5, %8, %8\n v_fma_f32 %6, %6, %8, %8\n v_fma_f32 %7, %7, %8, %8\n"
+                         : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7) : "v"(0.5f));
+        } else if (OP == 7) {  // v_rcp_f32 + v_div_scale + v_div_fmas + v_div_fixup mix as in one IEEE division (approx: 2 scale, rcp, 6 fma, fmas, fixup)
+            asm volatile("v_div_scale_f32 %0, vcc, %1, %2, %1\n v_rcp_f32 %3, %0\n v_fma_f32 %4, %0, %3, %3\n v_fma_f32 %4, %4, %3, %3\n"
+                         "v_fma_f32 %4, %4, %3, %3\n v_fma_f32 %4, %4, %3, %3\n v_div_fmas_f32 %4, %4, %3, %0\n v_div_fixup_f32 %5, %4, %2, %1\n"
+                         : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5) : : "vcc");
+        } else if (OP == 8) {  // v_mov_b32 from / to AGPR
+            asm volatile("v_accvgpr_write_b32 a0, %0\n v_accvgpr_read_b32 %1, a0\n v_accvgpr_write_b32 a1, %2\n v_accvgpr_read_b32 %3, a1\n"
+                         "v_accvgpr_write_b32 a2, %4\n v_accvgpr_read_b32 %5, a2\n v_accvgpr_write_b32 a3, %6\n v_accvgpr_read_b32 %7, a3\n"
+                         : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7) : : "a0", "a1", "a2", "a3");
+        }
+    }
+    long long t1 = __builtin_amdgcn_s_memtime();
+    double s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7;
+    if (threadIdx.x == 0) out[blockIdx.x * 2] = (double)(t1 - t0) / (N_IT * 8.0);
+    if (s == 12345.678) out[1] = s;
+}
+template <int OP>
+void run(const char* name) {
+    double* d;
+    hipMalloc(&d, 4096 * sizeof(double));
+    for (int wpb : {64, 128, 256, 512}) {     // 1, 2, 4, 8 waves per CU-ish block: one block per CU
+        k<OP><<<256, wpb>>>(d, 1.0f, wpb);
+        hipDeviceSynchronize();
+        k<OP><<<256, wpb>>>(d, 1.0f, wpb);
+        hipDeviceSynchronize();
+        std::vector<double> h(512);
+        hipMemcpy(h.data(), d, 512 * sizeof(double), hipMemcpyDeviceToHost);
+        double m = 0;
+        for (int b = 0; b < 256; b++) m += h[2 * b];
+        printf("%-28s block %3d threads (%d wave/SIMD): %.2f cycles per instruction per wave\n", name, wpb, wpb / 256 ? wpb / 256 : 0, m / 256);
+    }
+    hipFree(d);
+}
+int main() {
+    run<0>("v_add_f64 x8 indep");
+    run<1>("v_cvt_f64_f32 x8");
+    run<2>("v_cvt_f32_f64 x8");
+    run<3>("v_add_f32 x8");
+    run<4>("v_add_f64 dependent");
+    run<5>("cascade chain add,cvt,add,cvt");
+    run<6>("v_fma_f32 x8");
+    run<7>("ieee div mix (8 ops)");
+    run<8>("accvgpr write/read");
+    return 0;
+}
