@@ -209,7 +209,7 @@ def roofline_boxfilter(torch, device, T, F, kw, nwin):
     g = torch.Generator(device=device)
     g.manual_seed(9)
     data = torch.randn((nwin, T, F), generator=g, device=device).abs_()
-    wimg = torch.rand((nwin, T, F), generator=g, device=device)
+    wimg = torch.rand((nwin, 2, T, F), generator=g, device=device)    # stage 1 input: weight, weight * data per window
     f4 = (torch.rand((nwin, T // 4, F), generator=g, device=device) < 0.05).to(torch.int32) * 0x01010101
     ow = torch.empty((nwin, T, F), device=device)
     oo = torch.empty((nwin, T, F), device=device)

@@ -268,13 +268,12 @@ int tri_bench_sumthreshold(const float *data, const double *mad, uint8_t *out,
  *            weight (!flag) and weight * data images, already divided by
  *            float32(2 r + 1) ** 4.
  *   stage 1: frequency-axis stage fused with the masked division of the
- *            rejection loop (flagging.py:506-513, 563-566).  Here the line axis
- *            of the INPUT is its contiguous one: `flags4` is reinterpreted as
- *            the float32 weight image and `data` as the weight * data image,
- *            both (n_win, n_line, n_col) with n_col positions per line; `data`
- *            also stands in for the (n_col, n_line) amplitude image; out_o
- *            (n_win, n_col, n_line) receives |data - background|, out_w is
- *            scratch.
+ *            rejection loop (flagging.py:506-513, 563-566).  `flags4` is a float32
+ *            array (n_win, 2, n_line, n_col): per window the time-filtered weight
+ *            image followed by the weight * data image, lines contiguous (n_col
+ *            positions each); `data` the amplitudes (n_win, n_col, n_line);
+ *            out_o (n_win, n_col, n_line) receives |data - background|, out_w
+ *            is scratch of the same size.
  * `variant`: 0 = the flagger's default route for this radius, 1 = LDS delay
  * lines only (K4b / K4c / multi-pass), 2 = register delay lines (K4r).
  */
@@ -310,6 +309,15 @@ int tri_test_median(const float *data, const uint8_t *flags, double *med,
                     int64_t n_win, int64_t rows, int64_t row_len,
                     const int64_t *seg_ends, int64_t n_seg_ends, int variant,
                     void *stream);
+
+/*
+ * Test hook: the register-ring box-filter kernels divide by the launch constant
+ * float32(2 r + 1) ** 4 (flagging.py:419) through its reciprocal with exact
+ * remainder corrections.  Runs that division on ALL 2^32 float32 bit patterns
+ * for one radius and counts the inputs whose result differs from the correctly
+ * rounded IEEE quotient (NaN results compare equal); must be 0.
+ */
+int tri_test_box_divide(int64_t radius, uint64_t *mismatches, void *stream);
 
 /* Device amplitude of complex64 samples, the |z| used at flagging.py:856
  * (libm hypotf semantics); exposed so the tests can pin it (golden G0). */

@@ -23,8 +23,12 @@ flags = torch.rand((W, T, F), generator=g, device=dev) < 0.05
 flags[:, :, ::50] = True
 # TF4 packing: byte k of word (q, c) = flag of time 4 q + k
 f4 = flags.view(torch.uint8).view(W, T // 4, 4, F).permute(0, 1, 3, 2).contiguous()
-wimg = (~flags).float() * 0.9 + 0.05 * torch.rand((W, T, F), generator=g, device=dev)   # stage 1: a weight image
-wimg[:, :, 1000:1200] = 0.0                                                          # fully flagged band -> NaN background
+# stage 1: per window the weight image followed by the weight * data image
+both = torch.empty((W, 2, T, F), device=dev)
+both[:, 1] = data
+both[:, 0] = (~flags).float() * 0.9 + 0.05 * torch.rand((W, T, F), generator=g, device=dev)
+both[:, 0, :, 1000:1200] = 0.0                                                       # fully flagged band -> NaN background
+wimg = both
 ow = [torch.empty((W, T, F), device=dev) for _ in range(2)]
 oo = [torch.empty((W, T, F), device=dev) for _ in range(2)]
 ms = C.c_float(0)

@@ -1,1 +1,2 @@
-for v in u2 u4 u8; do echo "== variant $v"; TRICOLOUR_AMD_LIB=$PWD/tricolour_amd/variants/lib_$v.so python scripts/median_bench.py --variants 5 2>&1 | grep variant; done
+python scripts/boxfilter_bench.py --win 252 --stage 0 --radii 17,21,32,43,54
+python scripts/boxfilter_bench.py --win 252 --stage 1 --radii 5,8,10,17,25,34,43

@@ -66,6 +66,21 @@ def test_hypotf_kat(gpu):
     assert ok.all(), "%d of %d amplitudes differ from hypotf" % ((~ok).sum(), ok.size)
 
 
+def test_division_by_box_denominator(gpu):
+    """The register-ring filter kernels divide by float32(2r+1)**4 through its reciprocal (box_divide):
+    every one of the 2^32 float32 inputs, for every radius those kernels accept (and beyond), must give
+    the correctly rounded IEEE quotient (flagging.py:419 is a plain float32 division)."""
+    import ctypes as C
+    from tricolour_amd import _lib
+    bad = {}
+    for r in list(range(1, 129)) + [166, 221, 277, 397, 795]:
+        n = C.c_uint64(0)
+        _lib.check(_lib.lib().tri_test_box_divide(r, C.byref(n), None))
+        if n.value:
+            bad[r] = n.value
+    assert not bad, "inputs whose quotient differs from IEEE division, per radius: %s" % bad
+
+
 def test_random_windows_multi_batch(gpu, oracle):
     """Several windows, tiny workspace budget -> several internal batches."""
     import os

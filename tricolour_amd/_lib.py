@@ -129,6 +129,7 @@ _SIGNATURES = {
     "tri_bench_boxfilter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                       C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(C.c_float), C.c_void_p]),
+    "tri_test_box_divide": (C.c_int, [C.c_int64, C.POINTER(C.c_uint64), C.c_void_p]),
     "tri_test_median": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                   C.c_int64, C.POINTER(C.c_int64), C.c_int64, C.c_int, C.c_void_p]),
     "tri_abs_c64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -32,6 +32,39 @@
 //          outputs swapped through the staging tiles and finished as
 //          |data - bg| (MODE 1) or bg + signed residual + NaN marks (MODE 2).
 // ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// Exact division by the launch constant b = float32(2r+1)**4 (flagging.py:419) through its
+// correctly rounded reciprocal y = RN(1/b) (host, box_reciprocal()):
+//     q = a y;  r = fma(-b, q, a);  q = fma(r, y, q);  r = fma(-b, q, a);  q = fma(r, y, q)
+// Two Newton-style corrections with exact remainders (Markstein's scheme) give RN(a / b)
+// whenever the first product a y is a normal number or +0; every other input (quotients in
+// the subnormal range, -0, infinities, NaNs) is redone with the IEEE division, once per block
+// of steps and only if some lane needed it.  tests/test_gpu_parity.py::test_division_by_box_denominator checks this predicate
+// EXHAUSTIVELY -- all 2^32 float32 inputs for every radius the kernels accept -- against the
+// hardware's correctly rounded division.  6 vector instructions instead of 14.
+// ---------------------------------------------------------------------------
+struct BoxDenom { float b, y; };
+// Branch-free form: the quotient by the reciprocal scheme, and the lanes for which it is proven exact
+// AND-ed into `okmask` (a wave lane mask in scalar registers).  The caller checks the mask once per block
+// of steps and redoes the block's divisions with box_divide_ieee() if any active lane dropped out.
+__device__ __forceinline__ float box_divide(float a, const BoxDenom dn, unsigned long long& okmask) {
+    float q = a * dn.y;
+    // class mask: -normal (bit 3), +0 (bit 6), +normal (bit 8)
+    okmask &= __builtin_amdgcn_ballot_w64(__builtin_amdgcn_classf(q, 0x148));
+    float r = __builtin_fmaf(-dn.b, q, a);
+    q = __builtin_fmaf(r, dn.y, q);
+    r = __builtin_fmaf(-dn.b, q, a);
+    q = __builtin_fmaf(r, dn.y, q);
+    return q;
+}
+__device__ __forceinline__ float box_divide_ieee(float a, const BoxDenom dn) { return a / dn.b; }
+// (test hook form: one quotient, exact for every input)
+__device__ __forceinline__ float box_divide_checked(float a, const BoxDenom dn) {
+    unsigned long long ok = ~0ull;
+    const float q = box_divide(a, dn, ok);
+    return ((ok >> (threadIdx.x & 63)) & 1ull) ? q : box_divide_ieee(a, dn);
+}
+
 // The cascade state of one line: KS register slots per stage + running sums.
 template <int KS, typename V, typename A>
 struct BoxLine {
@@ -132,8 +165,7 @@ k_boxt(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags,
     const int R2x = 2 * r;
     const int d = R2x - KS;                              // LDS slots per stage (host: even, >= 2 when HASL, else 0)
     // buffer addressing (host: window below 2^31 bytes): lane offset c * 4 + scalar row offset,
-    // no per-load 64-bit address arithmetic; data loads beyond the line end return 0 by the
-    // descriptor's range check
+    // no per-load 64-bit address arithmetic
     const unsigned rowb = (unsigned)C * 4u;
     const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(srcData + win * sws), 0, (int)((unsigned)n * rowb), 0x00020000);
@@ -162,14 +194,14 @@ k_boxt(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags,
     auto issue = [&](int t0) {
 #pragma unroll
         for (int q = 0; q < PF / 4; q++) {
-            const int t = t0 + 4 * q;
-            const unsigned w = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(frs, coff, (int)((unsigned)(t >> 2) * rowb), 0);
-            prew[q] = (t < n) ? w : 0x01010101u;         // beyond the line end: flagged (weight 0)
+            const int t = t0 + 4 * q;                    // (the scalar row offset is not range-checked: clamp it)
+            const unsigned w = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(frs, coff, t < n ? (int)((unsigned)(t >> 2) * rowb) : 0, 0);
+            prew[q] = (t < n) ? w : 0x01010101u;         // beyond the line end: flagged (weight 0, data ignored)
         }
         if (IMG == 1) {
 #pragma unroll
             for (int u = 0; u < PF; u++)
-                pre[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, coff, (int)((unsigned)(t0 + u) * rowb), 0));
+                pre[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, coff, t0 + u < n ? (int)((unsigned)(t0 + u) * rowb) : 0, 0));
         }
     };
     auto store = [&](int i, float y) {
@@ -218,46 +250,48 @@ k_boxt(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags,
 
 // ---- frequency-axis stage fused with the masked division ---------------------------
 // Input images stored transposed: line c is row c of a [C][ld] array (the time-axis
-// stage's TF output), staged PF positions at a time through an LDS tile per image
-// (row segments in, one value per thread and step out).  A workgroup of two waves
-// filters BOTH images of 64 lines -- wave 0 the weight image, wave 1 the weight * data
-// image -- each step leaves the last stage's output in the tile slot its input came
-// from, and after every PF steps the two waves finish PF / 2 positions per line each:
+// stage's TF output; the data image img_gap elements after the weight image), staged PF
+// positions at a time through an LDS tile (row segments in, one value per lane and step out).  ONE WAVE filters BOTH images of 32 lines --
+// lanes 0-31 the weight image, lanes 32-63 the weight * data image -- so nothing is
+// shared between waves and the kernel has no workgroup barrier (LDS operations of one
+// wave execute in order; a wave-level fence keeps the compiler from moving them).  Each
+// step leaves the last stage's output in the tile slot its input came from, and after
+// every PF steps each half of the wave finishes PF / 2 positions per line:
 //     w = W / d^4, o = O / d^4, bg = (w == 0) ? NaN : o / w      (flagging.py:419, 506-513)
 //     MODE 1: dstO = |data - bg|                                  (rejection loop, :563-566)
 //     MODE 2: dstO = bg, dstW = data - bg, nanflag[line] = 1 on a NaN   (:576-578, :962)
 // The filtered images are never written.  Buffer addressing throughout (host: images and
 // outputs below 2^31 bytes per window).
-// grid (ceil(C / 64), W), block 128, dynamic LDS 2 * (4 * d * 64 + PF * 65) floats
+// grid (ceil(C / 32), W), block 64, dynamic LDS 4 * d * 64 + 2 * PF * 34 floats
+#define BOXF_TS 34                                             // tile row stride (floats): conflict-free column writes and row reads
 template <int KS, bool HASL, int MODE>
-__global__ void __launch_bounds__(128, boxr_waves_f(KS))
-k_boxf(const float* __restrict__ srcW, const float* __restrict__ srcO,
+__global__ void __launch_bounds__(64, boxr_waves_f(KS))
+k_boxf(const float* __restrict__ srcW, unsigned img_gap,
        float* __restrict__ dstW, float* __restrict__ dstO, const float* __restrict__ data,
-       int n, int C, int ld, int r, float denom, size_t sws_img, size_t dws, size_t ws_data,
+       int n, int C, int ld, int r, BoxDenom denom, size_t sws_img, size_t dws, size_t ws_data,
        uint8_t* __restrict__ nanflag) {
     extern __shared__ float cf_ring[];
     constexpr int PF = boxr_pf(KS);
     constexpr int UNR = boxr_lcm(KS, PF);
     constexpr int BT = 64;
-    constexpr int LPI = 64 / PF;                               // lines covered by one staging load instruction
-    constexpr int TS = BT + 1;                                 // tile row stride (floats)
-    const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0: weight image, 1: data image
-    const int lt = threadIdx.x & 63;
-    const int c0 = blockIdx.x * BT;
-    const int c = c0 + lt;
+    constexpr int LPI = 32 / PF;                               // lines covered by one staging load instruction (per image)
+    constexpr int TS = BOXF_TS;
+    const int lane = threadIdx.x;
+    const int half = lane >> 5;                                // 0: weight image, 1: data image
+    const int hl = lane & 31;
+    const int c0 = blockIdx.x * 32;
+    const int c = c0 + hl;
     const bool colok = c < C;
     const size_t win = blockIdx.y;
     const int R2x = 2 * r;
     const int d = R2x - KS;
-    float* ring = cf_ring + (size_t)half * 4 * d * BT + lt;    // element (slot, p) at ((slot*4)+p)*BT
-    float* tiles = cf_ring + (size_t)2 * 4 * d * BT;           // [2][PF][TS]
+    float* ring = cf_ring + lane;                              // element (slot, p) at ((slot*4)+p)*BT
+    float* tiles = cf_ring + (size_t)4 * d * BT;               // [2 images][PF][TS]
     float* tile = tiles + (size_t)half * PF * TS;
     if (HASL)
         for (int k = 0; k < 4 * d; k++) ring[(size_t)k * BT] = 0.0f;
 
-    const unsigned ldb = (unsigned)ld * 4u, rowb = (unsigned)C * 4u;
-    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((half == 0 ? srcW : srcO) + win * sws_img), 0, (int)((unsigned)C * ldb), 0x00020000);
+    const unsigned rowb = (unsigned)C * 4u;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(data + win * ws_data), 0, (int)((unsigned)n * rowb), 0x00020000);
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
@@ -265,43 +299,63 @@ k_boxf(const float* __restrict__ srcW, const float* __restrict__ srcO,
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(dstW + win * dws), 0, (int)((unsigned)n * rowb), 0x00020000);
 
-    // staging: element e = j * 64 + lt of a [64 lines][PF positions] patch: line = e / PF,
+    // staging: element e = j * 32 + hl of this half's [32 lines][PF positions] patch: line = e / PF,
     // position = e % PF -> PF consecutive lanes read PF * 4 contiguous bytes of one row.
-    // Rows beyond C fall outside the descriptor and read 0; positions beyond n are masked.
-    const int s_pos = lt % PF;
-    const int s_line0 = lt / PF;                               // + LPI j
-    const int s_off = (int)((unsigned)s_line0 * ldb) + s_pos * 4;
+    // Lines beyond C and positions beyond n are masked.
+    const int s_pos = hl % PF;
+    const int s_line0 = hl / PF;                               // + LPI j
+    // (the data image of a window starts img_gap elements after its weight image: one descriptor
+    //  spans both, the data-image half of the wave adds the gap to its lane offset)
+    const unsigned ldb = (unsigned)ld * 4u;
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(srcW + win * sws_img), 0, (int)((img_gap + (unsigned)C * (unsigned)ld) * 4u), 0x00020000);
+    const int s_off = (int)((unsigned)s_line0 * ldb) + s_pos * 4 + (half ? (int)(img_gap * 4u) : 0);
     float pre[PF];
     auto issue = [&](int t0) {
         const int sbase = (int)((unsigned)c0 * ldb) + t0 * 4;
-        if (t0 + PF <= n) {
+        if (t0 + PF <= n && c0 + 32 <= C) {
 #pragma unroll
             for (int j = 0; j < PF; j++)
                 pre[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srs, s_off, sbase + (int)((unsigned)(LPI * j) * ldb), 0));
         } else {
+            // lines beyond C / positions beyond n are masked (and their addresses kept inside the window)
             const bool tok = t0 + s_pos < n;
 #pragma unroll
             for (int j = 0; j < PF; j++) {
-                const float v = (t0 < n) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srs, s_off, sbase + (int)((unsigned)(LPI * j) * ldb), 0)) : 0.0f;
-                pre[j] = tok ? v : 0.0f;
+                const bool ok = tok && (c0 + LPI * j + s_line0 < C);
+                const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srs, ok ? s_off + sbase + (int)((unsigned)(LPI * j) * ldb) : 0, 0, 0));
+                pre[j] = ok ? v : 0.0f;
             }
         }
     };
-    auto exchange = [&]() {
-        __syncthreads();                                         // previous tile (and hand-over) fully consumed
-#pragma unroll
-        for (int j = 0; j < PF; j++) tile[s_pos * TS + LPI * j + s_line0] = pre[j];
-        __syncthreads();
+    // LDS traffic of this wave only: order it against the compiler, not against other waves
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    // this thread finishes positions u in [PF/2 half, PF/2 half + PF/2) of a block; their
-    // data samples are requested at the top of the block
-    const int coff = (colok ? c : 0) * 4;
+    // this lane finishes positions u in [PF/2 half, PF/2 half + PF/2) of a block; their
+    // data samples are requested at the top of the block.  Everything that depends on the
+    // half sits in ONE lane offset (hoff) / one LDS base (eb): the per-position parts are
+    // scalar row offsets and immediates.
+    const int hrow = (PF / 2) * half;                            // first position of this half within a block
+    const int hoff = (colok ? c : 0) * 4 + (int)((unsigned)hrow * rowb);
+    const float* eb = tiles + (size_t)hrow * TS + hl;            // weight tile; the data tile is PF * TS further
     float dpre[PF / 2];
-    auto issue_data = [&](int m0) {
+    auto issue_data = [&](int m0, bool fast) {
+        const int i0 = m0 - 3 - 4 * r;                           // position of u = 0 (scalar)
+        if (fast) {
 #pragma unroll
-        for (int k = 0; k < PF / 2; k++) {
-            const int i = m0 + (PF / 2) * half + k - 3 - 4 * r;
-            dpre[k] = (i >= 0 && i < n) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, coff, (int)((unsigned)i * rowb), 0)) : 0.0f;
+            for (int k = 0; k < PF / 2; k++)
+                dpre[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, hoff, (int)((unsigned)(i0 + k) * rowb), 0));
+        } else {
+#pragma unroll
+            for (int k = 0; k < PF / 2; k++) {
+                const int i = i0 + hrow + k;
+                const bool ok = i >= 0 && i < n;
+                const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ok ? (colok ? c : 0) * 4 + (int)((unsigned)i * rowb) : 0, 0, 0));
+                dpre[k] = ok ? v : 0.0f;
+            }
         }
     };
 
@@ -316,60 +370,72 @@ k_boxf(const float* __restrict__ srcW, const float* __restrict__ srcO,
 #pragma unroll
         for (int b = 0; b < UNR / PF; b++) {
             const int m0 = mb + b * PF;
-            if (m0 < total) {                                    // uniform over the workgroup
-                exchange();                                      // tile of positions [m0, m0 + PF) in LDS
+            if (m0 < total) {
+                wave_sync();                                     // previous tile (and hand-over) fully consumed
+#pragma unroll
+                for (int j = 0; j < PF; j++) tile[s_pos * TS + LPI * j + s_line0] = pre[j];
+                wave_sync();                                     // tile of positions [m0, m0 + PF) in LDS
                 issue(m0 + PF);                                  // next tile's loads stay in flight during the arithmetic
-                issue_data(m0);
                 const bool fast = m0 >= 4 * r + 3 && m0 + PF <= n;
+                issue_data(m0, fast);
                 // (the sample of step u + 1 is read before step u's LDS writes, so its latency hides
                 //  behind a whole step of arithmetic)
-                float xin = tile[lt];
+                float xin = tile[hl];
                 if (fast) {
 #pragma unroll
                     for (int u = 0; u < PF; u++) {
-                        const float xnext = (u + 1 < PF) ? tile[(u + 1) * TS + lt] : 0.0f;
+                        const float xnext = (u + 1 < PF) ? tile[(u + 1) * TS + hl] : 0.0f;
                         float* cell = ring + (size_t)lslot * BT4;
                         if (HASL) lslot = (lslot + 1 == d) ? 0 : lslot + 1;
                         const float* ncell = ring + (size_t)lslot * BT4;
-                        tile[u * TS + lt] = boxline_step<KS, float, double, HASL, true>(L, (b * PF + u) % KS, m0 + u, xin, n, R2x, cell, ncell, BT);
+                        tile[u * TS + hl] = boxline_step<KS, float, double, HASL, true>(L, (b * PF + u) % KS, m0 + u, xin, n, R2x, cell, ncell, BT);
                         xin = xnext;
                         if (BOXR_SCHED_EVERY > 0 && u % (BOXR_SCHED_EVERY > 0 ? BOXR_SCHED_EVERY : 1) == 0) __builtin_amdgcn_sched_barrier(0);
                     }
                 } else {
 #pragma unroll
                     for (int u = 0; u < PF; u++) {
-                        const float xnext = (u + 1 < PF) ? tile[(u + 1) * TS + lt] : 0.0f;
+                        const float xnext = (u + 1 < PF) ? tile[(u + 1) * TS + hl] : 0.0f;
                         float* cell = ring + (size_t)lslot * BT4;
                         if (HASL) lslot = (lslot + 1 == d) ? 0 : lslot + 1;
                         const float* ncell = ring + (size_t)lslot * BT4;
-                        tile[u * TS + lt] = boxline_step<KS, float, double, HASL, false>(L, (b * PF + u) % KS, m0 + u, xin, n, R2x, cell, ncell, BT);
+                        tile[u * TS + hl] = boxline_step<KS, float, double, HASL, false>(L, (b * PF + u) % KS, m0 + u, xin, n, R2x, cell, ncell, BT);
                         xin = xnext;
                         if (BOXR_SCHED_EVERY > 0 && u % (BOXR_SCHED_EVERY > 0 ? BOXR_SCHED_EVERY : 1) == 0) __builtin_amdgcn_sched_barrier(0);
                     }
                 }
                 if (m0 + PF - 1 - 3 - 4 * r >= 0) {              // an output position in this block (uniform)
-                    __syncthreads();
-                    const float* tw = tiles;
-                    const float* to = tiles + (size_t)PF * TS;
+                    wave_sync();                                 // both halves' outputs in the tiles
+                    const int i0 = m0 - 3 - 4 * r;
+                    unsigned long long okmask = ~0ull, active = 0;
+                    auto finish = [&](auto ieee_tag) {
+                        constexpr bool IEEE = decltype(ieee_tag)::value;
 #pragma unroll
-                    for (int k = 0; k < PF / 2; k++) {
-                        const int u = (PF / 2) * half + k;
-                        const int i = m0 + u - 3 - 4 * r;
-                        if ((fast || (i >= 0 && i < n)) && colok) {
-                            const float wv = tw[u * TS + lt] / denom;   // deferred flagging.py:419
-                            const float ov = to[u * TS + lt] / denom;
-                            const float bg = (wv == 0.0f) ? NAN : ov / wv;
-                            const int so = (int)((unsigned)i * rowb);
-                            if (MODE == 1) {
-                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fabsf(dpre[k] - bg)), ors, coff, so, 0);
-                            } else {
-                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bg), ors, coff, so, 0);
-                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dpre[k] - bg), wrs, coff, so, 0);
-                                line_nan |= isnan(bg);
+                        for (int k = 0; k < PF / 2; k++) {
+                            const int i = i0 + hrow + k;
+                            if ((fast || (i >= 0 && i < n)) && colok) {
+                                if (!IEEE) active |= __builtin_amdgcn_ballot_w64(true);
+                                // deferred flagging.py:419
+                                const float wv = IEEE ? box_divide_ieee(eb[k * TS], denom) : box_divide(eb[k * TS], denom, okmask);
+                                const float ov = IEEE ? box_divide_ieee(eb[(PF + k) * TS], denom) : box_divide(eb[(PF + k) * TS], denom, okmask);
+                                const float bg = (wv == 0.0f) ? NAN : ov / wv;
+                                // fast blocks: i0 + k >= 0, the half's rows ride in the lane offset
+                                const int vo = fast ? hoff : (c * 4 + (int)((unsigned)i * rowb));
+                                const int so = fast ? (int)((unsigned)(i0 + k) * rowb) : 0;
+                                if (MODE == 1) {
+                                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fabsf(dpre[k] - bg)), ors, vo, so, 0);
+                                } else {
+                                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bg), ors, vo, so, 0);
+                                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dpre[k] - bg), wrs, vo, so, 0);
+                                    line_nan |= isnan(bg);
+                                }
                             }
+                            if (BOXR_SCHED_EVERY > 0) __builtin_amdgcn_sched_barrier(0);
                         }
-                        if (BOXR_SCHED_EVERY > 0) __builtin_amdgcn_sched_barrier(0);
-                    }
+                    };
+                    finish(std::false_type{});
+                    // some quotient fell outside the reciprocal scheme's proven range: redo the block (rare)
+                    if ((okmask & active) != active) finish(std::true_type{});
                 }
             }
         }

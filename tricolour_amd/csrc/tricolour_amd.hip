@@ -47,6 +47,20 @@ float box_denominator(int64_t r) {
     return res;
 }
 
+// RN(1 / b) for the reciprocal-based exact division of the register-ring filter kernels
+// (box_divide): b and the candidates are 24-bit, so b * y is exact in float64 and the
+// candidate closest to 1 / b is found without rounding.
+BoxDenom box_reciprocal(float b) {
+    float y = (float)(1.0 / (double)b);
+    const float cand[3] = {std::nextafterf(y, 0.0f), y, std::nextafterf(y, INFINITY)};
+    double best = INFINITY;
+    for (float c : cand) {
+        const double e = std::fabs(1.0 - (double)b * (double)c);
+        if (e < best) { best = e; y = c; }
+    }
+    return BoxDenom{b, y};
+}
+
 struct Plan {
     int64_t T, F, Fa, avg, G;
     int64_t r0max, r1max;   // largest box radii along time / frequency
@@ -166,8 +180,10 @@ static void carve(const Plan& pl, int64_t Wb, void* base, size_t cap, bool dry, 
     ws->iter = b.get<uint8_t>(W * T * F);
     ws->dataTF = b.get<float>(W * N);
     ws->dataFT = b.get<float>(W * N);
-    ws->Aw = b.get<float>(W * (size_t)pl.PT * Fa);
-    ws->Ao = b.get<float>(W * (size_t)pl.PT * Fa);
+    // time-axis scratch: the weight and the weight * data image of a window sit next to each other
+    // (window stride 2 * PT * Fa), so one buffer descriptor of the fused frequency stage reaches both
+    ws->Aw = b.get<float>(W * 2 * (size_t)pl.PT * Fa);
+    ws->Ao = dry ? nullptr : ws->Aw + (size_t)pl.PT * Fa;
     ws->Bw = b.get<float>(W * (size_t)pl.PF * T);
     ws->Bo = b.get<float>(W * (size_t)pl.PF * T);
     ws->flagsTF = b.get<uint8_t>(W * N);
@@ -746,18 +762,22 @@ int launch_colfilter_tf(const Run& r, const float* srcW, const float* srcO, floa
 template <int KS, int MODE>
 int launch_boxf_ks(const Run& r, const float* srcW, const float* srcO, float* dstW, float* dstO, const float* data,
                    int n, int C, int ld, int rad, size_t sws_img, size_t dws, size_t ws_data, int64_t W, uint8_t* nanflag) {
-    const float denom = box_denominator(rad);
+    const BoxDenom denom = box_reciprocal(box_denominator(rad));
     const int d = 2 * rad - KS;
-    const size_t lds = (size_t)2 * ((size_t)4 * d * 64 + (size_t)boxr_pf(KS) * 65) * sizeof(float);
+    const size_t lds = ((size_t)4 * d * 64 + (size_t)2 * boxr_pf(KS) * BOXF_TS) * sizeof(float);
+    // one descriptor per window spans both images: the data image must follow the weight image closely
+    if (srcO <= srcW || ((uint64_t)(srcO - srcW) + (uint64_t)C * ld) * 4u >= (1ull << 31))
+        return set_err(TRI_EUNSUPPORTED, "fused frequency stage: the data image must follow the weight image within 2^31 bytes");
+    const unsigned gap = (unsigned)(srcO - srcW);
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boxf<KS, true, MODE>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     HIPCHK(attr);
-    dim3 grid((unsigned)cdiv(C, 64), (unsigned)W);
+    dim3 grid((unsigned)cdiv(C, 32), (unsigned)W);
     if (d > 0)
-        hipLaunchKernelGGL((k_boxf<KS, true, MODE>), grid, dim3(128), lds, r.st, srcW, srcO, dstW, dstO, data, n, C, ld, rad,
+        hipLaunchKernelGGL((k_boxf<KS, true, MODE>), grid, dim3(64), lds, r.st, srcW, gap, dstW, dstO, data, n, C, ld, rad,
                            denom, sws_img, dws, ws_data, nanflag);
     else
-        hipLaunchKernelGGL((k_boxf<KS, false, MODE>), grid, dim3(128), lds, r.st, srcW, srcO, dstW, dstO, data, n, C, ld, rad,
+        hipLaunchKernelGGL((k_boxf<KS, false, MODE>), grid, dim3(64), lds, r.st, srcW, gap, dstW, dstO, data, n, C, ld, rad,
                            denom, sws_img, dws, ws_data, nanflag);
     LAUNCHCHK();
     return TRI_OK;
@@ -854,7 +874,7 @@ int background2d(const Run& r) {
     int T = (int)pl.T, Fa = (int)pl.Fa, G = (int)pl.G;
     int64_t W = r.Wb;
     size_t N = (size_t)T * Fa;
-    size_t wsA = (size_t)pl.PT * Fa, wsB = (size_t)pl.PF * T;
+    size_t wsA = 2 * (size_t)pl.PT * Fa, wsB = (size_t)pl.PF * T;   // Aw / Ao interleaved per window (carve)
     // Background flags live in FT layout (ws.bgfFT).  For the time-axis stage
     // they are needed per (time, channel) column thread: either as a TF byte
     // image (general case) or, when T % 4 == 0, packed four times per word
@@ -886,7 +906,7 @@ int background2d(const Run& r) {
         bool direct_ft = false;
         // frequency stage able to read the time stage's TF images itself (no transposes)
         // register-ring fused frequency stage (signed 32-bit buffer offsets: window below 2^31 bytes)
-        const int ksf = ((uint64_t)N * 4u < (1ull << 31) && (uint64_t)wsA * 4u < (1ull << 31)) ? boxr_pick_ks_f(r1) : 0;
+        const int ksf = ((uint64_t)N * 4u < (1ull << 31) && ((uint64_t)(ws.Ao - ws.Aw) + N) * 4u < (1ull << 31)) ? boxr_pick_ks_f(r1) : 0;
         const bool tin4 = !ksf && !colfilter_t_usable(r1) && colfilter_t4_usable(r1);
         const bool tin = ksf > 0 || colfilter_t_usable(r1) || tin4;
         float* den_t_ptr = tin ? nullptr : &den_t;
@@ -1392,16 +1412,17 @@ extern "C" int tri_bench_boxfilter(const float* data, const uint8_t* flags4, flo
             // frequency-axis stage + masked division from TF images (line = time row, n_col positions):
             // the flagger's route for this radius (fused register / LDS ring kernel, or lane-per-stage
             // filter followed by the division kernel)
-            const float* srcW = reinterpret_cast<const float*>(flags4);
+            const float* srcW = reinterpret_cast<const float*>(flags4);   // (n_win, 2, n_line, n_col): weight, weight * data
+            const float* srcO = srcW + N;
             const int T = (int)n_line, Fa = (int)n_col, rad = (int)radius;
             const int ksf = boxr_pick_ks_f(rad);
             if (ksf > 0) {
-                rc = launch_boxf<1>(r, ksf, srcW, data, out_w, out_o, data, Fa, T, Fa, rad, N, N, N, n_win, nullptr);
+                rc = launch_boxf<1>(r, ksf, srcW, srcO, out_w, out_o, data, Fa, T, Fa, rad, 2 * N, N, N, n_win, nullptr);
             } else if (colfilter_tf_usable(rad)) {
-                rc = launch_colfilter_tf<1>(r, srcW, data, out_w, out_o, data, Fa, T, Fa, rad, N, N, N, n_win, nullptr);
+                rc = launch_colfilter_tf<1>(r, srcW, srcO, out_w, out_o, data, Fa, T, Fa, rad, 2 * N, N, N, n_win, nullptr);
             } else if (colfilter_t4_usable(rad)) {
                 float den_f = 0.0f;
-                rc = launch_colfilter_t4(r, srcW, data, out_w, out_o, Fa, T, Fa, rad, N, N, n_win, &den_f);
+                rc = launch_colfilter_t4(r, srcW, srcO, out_w, out_o, Fa, T, Fa, rad, 2 * N, N, n_win, &den_f);
                 if (rc == TRI_OK) rc = launch_masked_div<1>(r, out_w, out_o, data, N, N, N, n_win, den_f);
             } else {
                 rc = set_err(TRI_EUNSUPPORTED, "no single-sweep frequency stage for radius %d", rad);
@@ -1418,6 +1439,35 @@ extern "C" int tri_bench_boxfilter(const float* data, const uint8_t* flags4, flo
     *ms_per_launch = ms / repeats;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    return TRI_OK;
+}
+
+// Test hook: exhaustive check of box_divide() for one radius (see include/tricolour_amd.h)
+__global__ void k_check_box_divide(BoxDenom dn, unsigned long long* out) {
+    unsigned long long bad = 0;
+    const unsigned stride = gridDim.x * blockDim.x;
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    for (unsigned long long it = 0; it < (1ull << 32) / stride; it++, i += stride) {
+        const float a = __uint_as_float(i);
+        const float q = box_divide_checked(a, dn);
+        const float e = a / dn.b;
+        if (!((__float_as_uint(q) == __float_as_uint(e)) || (isnan(q) && isnan(e)))) bad++;
+    }
+    if (bad) atomicAdd(out, bad);
+}
+extern "C" int tri_test_box_divide(int64_t radius, uint64_t* mismatches, void* stream) {
+    if (!mismatches || radius < 0 || radius > (1 << 20)) return set_err(TRI_EINVAL, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long* d = nullptr;
+    HIPCHK(hipMalloc(&d, sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(d, 0, sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(k_check_box_divide, dim3(4096), dim3(256), 0, st, box_reciprocal(box_denominator(radius)), d);
+    LAUNCHCHK();
+    unsigned long long h = 0;
+    HIPCHK(hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    (void)hipFree(d);
+    *mismatches = h;
     return TRI_OK;
 }
 
