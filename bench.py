@@ -419,6 +419,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-other-params", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="run only the per-kernel roofline legs (what the rocprofv3 --pmc passes of profiles/ wrap)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher rehearsal without a GPU: every rank joins a gloo group, rank 0 prints the rank count")
     args = ap.parse_args()
@@ -485,6 +487,12 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.roofline_only:
+        nwin = min(nbl * ncorr, 1008 if wl != "ska" else 64)
+        print(json.dumps({"roofline": [roofline_sumthreshold(torch, device, T, F, kw, nwin)] +
+                          roofline_boxfilter(torch, device, T, F, kw, nwin)}))
+        return
 
     extra = {}
     nvis_step = nbl * ncorr * T * F
@@ -600,7 +608,7 @@ def main():
         flagging.release_workspace()
         torch.cuda.empty_cache()
     if rank == 0:
-        nwin = min(nbl * ncorr, 1008 if wl != "ska" else 16)
+        nwin = min(nbl * ncorr, 1008 if wl != "ska" else 64)
         if not args.no_roofline:
             res["roofline"] = [roofline_sumthreshold(torch, device, T, F, kw, nwin)] + \
                 roofline_boxfilter(torch, device, T, F, kw, nwin)
