@@ -16,7 +16,10 @@ vis.real = rs.standard_normal(shape)
 vis.imag = rs.standard_normal(shape)
 flags = rs.uniform(size=shape) < 0.02
 ref = tricolour_amd.sum_threshold_flagger(vis, flags)
-for threads in (1, 2, 4):
+flagging_threads = None
+for threads in (1, 2, 4, 8):
+    from tricolour_amd import flagging
+    flagging.set_num_threads(threads)
     with ThreadPoolExecutor(threads) as pool:
         list(pool.map(lambda i: tricolour_amd.sum_threshold_flagger(vis, flags), range(threads)))   # warm workspaces
         t0 = time.time()

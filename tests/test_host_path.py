@@ -1,0 +1,82 @@
+"""The drop-in path as the dask graph drives it: host (numpy) blocks handed to the per-block callable of
+tricolour_amd.dask_wrappers from a ThreadPool (tricolour/dask_wrappers.py:23-46, app.py:266-271), plus the
+stream / workspace hand-over rules of host-side inputs."""
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def test_blockwise_layer_emulation_threadpool_vs_reference_capture(gpu):
+    """G9 holds a block set the REFERENCE's own graph processed (pack_data -> dask_wrappers.sum_threshold_flagger
+    -> unpack_data under oracle B).  dask cannot be imported next to torch here, so the blockwise layer is
+    emulated: the wrapper module's per-block callable, three unequal `bl` chunks (chunking is along bl only,
+    app.py:451), dask's ThreadPool -- real kernels -- and the blocks re-joined along bl."""
+    from tricolour_amd import dask_wrappers as dw
+    d, kw = load_golden("G9_config1_plumbing.npz")
+    vis, flags = d["vis_windows"], d["flag_windows"]
+    bounds = [0, 1, 4, 6]                                # chunks of 1, 3 and 2 baselines
+    blocks = [(vis[a:b], flags[a:b]) for a, b in zip(bounds, bounds[1:])]
+    with ThreadPoolExecutor(3) as pool:
+        outs = list(pool.map(lambda vf: dw.amd_sum_threshold_flagger(vf[0], vf[1], **kw), blocks))
+    assert all(isinstance(o, np.ndarray) and o.dtype == np.bool_ for o in outs)
+    out = np.concatenate(outs, axis=0)
+    assert np.array_equal(out, d["out_windows"])
+
+
+def test_cpu_tensor_input_and_mixed_streams(gpu, oracle):
+    """host inputs that are not numpy (CPU torch tensors) come back as a device tensor produced on
+    the per-thread side stream -- it must be safe to use on the caller's stream at once; and a device-tensor
+    call followed by a numpy call (two streams in flight from one thread) must not share scratch."""
+    import torch
+    rs = np.random.RandomState(21)
+    shape = (3, 2, 96, 160)
+    vis = (rs.standard_normal(shape) + 1j * rs.standard_normal(shape)).astype(np.complex64)
+    vis[..., 50] *= 7
+    flags = rs.uniform(size=shape) < 0.04
+    kw = dict(num_major_iterations=2)
+    exp = oracle.sum_threshold_flagger(vis, flags, **kw)
+    vis2 = np.ascontiguousarray(vis[::-1])
+    exp2 = oracle.sum_threshold_flagger(vis2, flags, **kw)
+    # CPU tensors in -> device tensor out, consumed immediately on the current stream
+    out_t = gpu.sum_threshold_flagger(torch.from_numpy(vis), torch.from_numpy(flags), **kw)
+    assert out_t.is_cuda
+    cnt = out_t.sum()                                    # a kernel on the caller's stream, no explicit sync
+    assert int(cnt.item()) == int(exp.sum())
+    assert np.array_equal(out_t.cpu().numpy(), exp)
+    # asynchronous device-tensor call on the current stream, then a numpy call (side stream) before syncing
+    vd, fd = torch.from_numpy(vis).cuda(), torch.from_numpy(flags).cuda()
+    for _ in range(3):
+        o1 = gpu.sum_threshold_flagger(vd, fd, **kw)     # not synchronised
+        o2 = gpu.sum_threshold_flagger(vis2, flags, **kw)
+        assert np.array_equal(o2, exp2)
+        assert np.array_equal(o1.cpu().numpy(), exp)
+
+
+def test_wide_input_types(gpu, oracle):
+    """The reference takes real or complex input of either width (flagging.py:830-835, 856-859): float64
+    amplitudes and complex128 visibilities that are exactly representable in the narrow type give the
+    narrow type's flags."""
+    rs = np.random.RandomState(8)
+    shape = (2, 1, 64, 96)
+    vis = (rs.standard_normal(shape) + 1j * rs.standard_normal(shape)).astype(np.complex64)
+    vis[..., 30] *= 9
+    vis[0, 0, 5, 7] = np.nan
+    flags = rs.uniform(size=shape) < 0.05
+    kw = dict(num_major_iterations=2)
+    exp = oracle.sum_threshold_flagger(vis, flags, **kw)
+    out64 = gpu.sum_threshold_flagger(vis, flags, **kw)
+    assert np.array_equal(out64, exp)
+    amp = np.abs(rs.standard_normal(shape)).astype(np.float32) + 2
+    amp[..., 11] *= 8
+    expa = oracle.sum_threshold_flagger(amp, flags, **kw)
+    assert np.array_equal(gpu.sum_threshold_flagger(amp.astype(np.float64), flags, **kw), expa)
+    # complex128 whose amplitude is exact in float64: real-only and imaginary-only samples
+    z = np.zeros(shape, np.complex128)
+    z.real[:, :, ::2] = amp[:, :, ::2]
+    z.imag[:, :, 1::2] = -amp[:, :, 1::2].astype(np.float64)
+    assert np.array_equal(gpu.sum_threshold_flagger(z, flags, **kw), expa)

@@ -68,12 +68,13 @@ def prepare_params(ntime, nchan, outlier_nsigma=4.5,
 
 
 def _workspace(torch, device, nbytes):
-    """Per-thread, per-device workspace tensor (grown on demand): calls from
-    the threads of a dask ThreadPool never share scratch memory."""
+    """Per-thread, per-device, per-STREAM workspace tensor (grown on demand): calls from the
+    threads of a dask ThreadPool never share scratch memory, and neither do two pipelines
+    that one thread has in flight on different streams."""
     cache = getattr(_tls, "ws", None)
     if cache is None:
         cache = _tls.ws = {}
-    key = (device.type, device.index)
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     t = cache.get(key)
     if t is None or t.numel() < nbytes:
         cache[key] = None
@@ -83,17 +84,33 @@ def _workspace(torch, device, nbytes):
 
 
 def release_workspace():
-    """Drops this thread's cached device workspace."""
+    """Drops this thread's cached device workspaces."""
     _tls.ws = {}
+
+
+def set_num_threads(n):
+    """Declares how many host threads will call into the library concurrently (dask's
+    ThreadPool size): every thread then sizes its workspace against 1/n of the device
+    instead of against whatever the other threads have left free.  Also settable through
+    the environment variable TRICOLOUR_AMD_THREADS."""
+    global _declared_threads
+    _declared_threads = max(1, int(n))
+
+
+_declared_threads = None
 
 
 def _workspace_budget(torch, device):
     env = os.environ.get("TRICOLOUR_AMD_WORKSPACE_GB")
     if env:
         return int(float(env) * (1 << 30))
-    free, _total = torch.cuda.mem_get_info(device)
-    cached = getattr(_tls, "ws", {}).get((device.type, device.index))
-    have = cached.numel() if cached is not None else 0
+    free, total = torch.cuda.mem_get_info(device)
+    cached = [t for k, t in getattr(_tls, "ws", {}).items() if t is not None and k[:2] == (device.type, device.index)]
+    have = max([t.numel() for t in cached], default=0)
+    nthreads = _declared_threads or int(os.environ.get("TRICOLOUR_AMD_THREADS", "0") or 0)
+    if nthreads > 1:
+        # a fixed share of the device, whatever is free right now
+        return max(int(0.6 * total / nthreads), have)
     return max(int(0.6 * free), have)
 
 
@@ -135,7 +152,7 @@ def _host_call_stream(torch, vis, flags):
 
 
 def _as_device_inputs(torch, vis, flags):
-    """Returns (vis_tensor, flags_u8_tensor, vis_dtype_code, from_numpy)."""
+    """Returns (vis_tensor, flags_u8_tensor, vis_dtype_code, from_numpy, device)."""
     from_numpy = isinstance(vis, np.ndarray) or isinstance(flags, np.ndarray)
     device = None
     if torch.is_tensor(vis) and vis.is_cuda:
@@ -147,7 +164,9 @@ def _as_device_inputs(torch, vis, flags):
 
     def to_t(a):
         if isinstance(a, np.ndarray):
-            return torch.from_numpy(np.ascontiguousarray(a)).to(device, non_blocking=False)
+            # pageable host memory: the driver's own staged copy runs at the link rate on this platform
+            # (56 GB/s measured, scripts/host_copy_rates.py) -- faster than copying into pinned buffers first
+            return torch.from_numpy(np.ascontiguousarray(a)).to(device, non_blocking=True)
         if torch.is_tensor(a):
             return a.to(device)
         return torch.as_tensor(np.asarray(a)).to(device)
@@ -163,9 +182,11 @@ def _as_device_inputs(torch, vis, flags):
         # one round-to-nearest (flagging.py:856-859), which is what the cast
         # does when no channel averaging follows
         code = -64
+    elif v.dtype == torch.complex128:
+        code = -128
     else:
-        raise TypeError("tricolour_amd.sum_threshold_flagger: visibilities must be "
-                        "complex64 or float32 (got %s)" % v.dtype)
+        raise TypeError("tricolour_amd.sum_threshold_flagger: visibilities must be real or "
+                        "complex floating point (got %s)" % v.dtype)
     if f.dtype == torch.bool:
         f8 = f.contiguous().view(torch.uint8)
     elif f.dtype in (torch.uint8, torch.int8):
@@ -210,18 +231,39 @@ def sum_threshold_flagger(vis, flags, outlier_nsigma=4.5,
     torch = _require_gpu()
     side = _host_call_stream(torch, vis, flags)
     if side is not None:
+        caller = torch.cuda.current_stream(side.device)
+        side.wait_stream(caller)          # anything the caller queued (e.g. a CPU tensor being produced) comes first
         with torch.cuda.stream(side):
-            return _flag_on_current_stream(torch, lib, p, vis, flags, average_freq, _debug)
+            out = _flag_on_current_stream(torch, lib, p, vis, flags, average_freq, _debug)
+        if torch.is_tensor(out) and out.is_cuda:
+            # host inputs that were not numpy (CPU tensors, lists) get a device tensor back: hand it
+            # over to the caller's stream properly
+            caller.wait_stream(side)
+            out.record_stream(caller)
+        return out
     return _flag_on_current_stream(torch, lib, p, vis, flags, average_freq, _debug)
 
 
 def _flag_on_current_stream(torch, lib, p, vis, flags, average_freq, _debug):
     nbl, ncorr, ntime, nchan = (int(s) for s in vis.shape)
     v, f8, code, from_numpy, device = _as_device_inputs(torch, vis, flags)
-    if code == -64:
+    if code in (-64, -128):
+        # float64 / complex128 input (the reference accepts "real or complex", flagging.py:830-835):
+        # its amplitude is np.abs in float64 -- for complex128 numba's hypot(re, im) -- and enters the
+        # float32 accumulator `value` through one round-to-nearest (flagging.py:856-859).  Without
+        # channel averaging that rounded amplitude IS the averaged sample, so it can be formed up front.
         if int(average_freq) != 1:
-            raise NotImplementedError("float64 visibilities with average_freq > 1")
-        v = v.abs().to(torch.float32)
+            raise NotImplementedError("float64 / complex128 visibilities with average_freq > 1 "
+                                      "(the shipped strategies all use average_freq = 1)")
+        if code == -128:
+            re, im = v.real, v.imag
+            # torch.hypot is correctly rounded on this path to within 1 ulp of float64: far inside the
+            # float32 rounding that follows; (inf, nan) -> inf like C99 hypot
+            amp = torch.hypot(re, im)
+            amp = torch.where(torch.isinf(re) | torch.isinf(im), torch.full_like(amp, float("inf")), amp)
+            v = amp.to(torch.float32)
+        else:
+            v = v.abs().to(torch.float32)
         code = _lib.TRI_VIS_F32
     n_cp = nbl * ncorr
     with torch.cuda.device(device):
