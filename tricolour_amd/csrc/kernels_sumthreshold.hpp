@@ -310,8 +310,11 @@ k_colst_fused(const float* __restrict__ data, const double* __restrict__ med,
 // so every load has 16..31 ticks to land.
 // grid (ceil(C/BLK), G, W), block BLK;  needs L * C * 4 < 2^31
 // ---------------------------------------------------------------------------
+#ifndef ST_MAXBLK
+#define ST_MAXBLK 256
+#endif
 template <int W0, int W1, int W2, int W3>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(ST_MAXBLK, ST_MAXBLK >= 1024 ? 1 : 2)
 k_colst_mask(const float* __restrict__ data, const double* __restrict__ med,
              uint8_t* __restrict__ out, const int64_t* __restrict__ chunk_ends,
              StFusedArgs fa, double thr_scale, int L, int C, int G, size_t ws_data,
@@ -416,12 +419,14 @@ k_colst_mask(const float* __restrict__ data, const double* __restrict__ med,
                     const int q = (PH - D[j]) & (UN - 1);
                     const double x = xd[q & 7];
                     double cl = x;
+#ifndef ST_ABLATE_CLAMP      // timing-only builds (scripts/st_floor.sh): results are wrong on purpose
                     if (j > 0) {
                         const uint64_t cp = fP[q] & __builtin_amdgcn_ballot_w64(x > thr[j]);
                         const uint64_t cn = fN[q] & __builtin_amdgcn_ballot_w64(x < -thr[j]);
                         const bool m = __builtin_amdgcn_inverse_ballot_w64(cp | cn);
                         cl = m ? __builtin_copysign(thr[j], x) : x;
                     }
+#endif
                     const double cs = cum[j] + cl;
                     cum[j] = cs;
                     const int slot = (PH - D[j] + 1) & (w - 1);
@@ -432,6 +437,12 @@ k_colst_mask(const float* __restrict__ data, const double* __restrict__ med,
                     else { old = r3[slot & (W3 - 1)]; r3[slot & (W3 - 1)] = cs; }
                     const double S = cs - old;
                     const bool full = fast || i + 1 - w >= 0;   // window complete
+#ifdef ST_ABLATE_HITS
+                    if (j < 3) {
+                        asm volatile("" :: "v"(S));      // keep the rolling sum alive (methodology rule 17)
+                        if (j == 0) { fP[q] = 0; fN[q] = 0; }
+                    } else
+#endif
                     if (j < 3) {
                         uint64_t hp = __builtin_amdgcn_ballot_w64(S > T[j]);
                         uint64_t hn = __builtin_amdgcn_ballot_w64(S < -T[j]);

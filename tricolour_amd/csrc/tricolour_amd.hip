@@ -634,6 +634,7 @@ int launch_colst(const Run& r, const StWin& sw, const float* data, const double*
                  size_t ws_out, int64_t W) {
     double thr_scale = r.p->outlier_nsigma * TRI_MAD_NORMAL;  // flagging.py:623
     int blk = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
+    if (const char* e = getenv("TRI_ST_BLK")) { int b = atoi(e); if (b >= 64 && b <= ST_MAXBLK && C >= b) blk = b; }
     dim3 grid((unsigned)cdiv(C, blk), (unsigned)G, (unsigned)W);
     if (st_use_fused(sw)) {
         StFusedArgs fa;
@@ -1350,6 +1351,7 @@ extern "C" int tri_bench_sumthreshold(const float* data, const double* mad, uint
     HIPCHK(hipEventCreate(&e1));
     int C = (int)n_col, L = (int)n_line;
     int blk = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
+    if (const char* e = getenv("TRI_ST_BLK")) { int b = atoi(e); if (b >= 64 && b <= ST_MAXBLK && C >= b) blk = b; }
     dim3 grid((unsigned)cdiv(C, blk), 1, (unsigned)n_win);
     size_t ws = (size_t)n_line * n_col;
     bool can_fuse = sw.nw == 4 && sw.w[0] == 1 && sw.w[1] == 2 && sw.w[2] == 4 && sw.w[3] == 8;
