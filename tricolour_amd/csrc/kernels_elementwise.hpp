@@ -653,6 +653,65 @@ __global__ void k_pack(const float2* __restrict__ data, const uint8_t* __restric
     }
 }
 
+// NC = 1, 2 or 4 correlations: the (chan, corr) samples of a thread are one 8 / 16 / 32-byte piece of the row --
+// vector loads (the scalar form reads every cache line of the row once per correlation)
+template <int NC>
+__global__ void k_pack_v(const float2* __restrict__ data, const uint8_t* __restrict__ flag,
+                         const int32_t* __restrict__ row_bl, const int32_t* __restrict__ row_time,
+                         int nchan, int nbl, int ntime, float2* __restrict__ vw, uint8_t* __restrict__ fw) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t r = blockIdx.y;
+    if (f >= nchan) return;
+    const int bl = row_bl[r], t = row_time[r];
+    if (bl < 0 || bl >= nbl || t < 0 || t >= ntime) return;
+    const size_t i = (r * nchan + f) * (size_t)NC;
+    float2 v[NC];
+    uint8_t fl[NC];
+    if (NC == 4) {
+        const float4 a = reinterpret_cast<const float4*>(data + i)[0], b = reinterpret_cast<const float4*>(data + i)[1];
+        v[0] = make_float2(a.x, a.y); v[1 % NC] = make_float2(a.z, a.w);
+        v[2 % NC] = make_float2(b.x, b.y); v[3 % NC] = make_float2(b.z, b.w);
+        const uchar4 q = *reinterpret_cast<const uchar4*>(flag + i);
+        fl[0] = q.x; fl[1 % NC] = q.y; fl[2 % NC] = q.z; fl[3 % NC] = q.w;
+    } else if (NC == 2) {
+        const float4 a = *reinterpret_cast<const float4*>(data + i);
+        v[0] = make_float2(a.x, a.y); v[1 % NC] = make_float2(a.z, a.w);
+        const uchar2 q = *reinterpret_cast<const uchar2*>(flag + i);
+        fl[0] = q.x; fl[1 % NC] = q.y;
+    } else {
+        v[0] = data[i];
+        fl[0] = flag[i];
+    }
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const size_t o = (((size_t)bl * NC + c) * ntime + t) * (size_t)nchan + f;
+        vw[o] = v[c];
+        fw[o] = fl[c];
+    }
+}
+
+template <int NC>
+__global__ void k_unpack_v(const uint8_t* __restrict__ fw, const int32_t* __restrict__ row_bl,
+                           const int32_t* __restrict__ row_time, int nchan, int nbl, int ntime,
+                           uint8_t* __restrict__ out, int any_corr) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t r = blockIdx.y;
+    if (f >= nchan) return;
+    const int bl = row_bl[r], t = row_time[r];
+    const bool ok = !(bl < 0 || bl >= nbl || t < 0 || t >= ntime);
+    uint8_t v[NC];
+    uint8_t any = 0;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        v[c] = ok ? fw[(((size_t)bl * NC + c) * ntime + t) * (size_t)nchan + f] : 0;
+        any |= v[c] ? 1 : 0;
+    }
+    const size_t i = (r * nchan + f) * (size_t)NC;
+    if (NC == 4) *reinterpret_cast<uchar4*>(out + i) = any_corr ? make_uchar4(any, any, any, any) : make_uchar4(v[0], v[1 % NC], v[2 % NC], v[3 % NC]);
+    else if (NC == 2) *reinterpret_cast<uchar2*>(out + i) = any_corr ? make_uchar2(any, any) : make_uchar2(v[0], v[1 % NC]);
+    else out[i] = any_corr ? any : v[0];
+}
+
 // any_corr: "flag entire visibility if any correlations are flagged"
 // (apps/tricolour/app.py:479-480) fused into the gather
 __global__ void k_unpack(const uint8_t* __restrict__ fw, const int32_t* __restrict__ row_bl,

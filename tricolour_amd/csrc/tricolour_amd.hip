@@ -1298,10 +1298,23 @@ extern "C" int tri_pack_data(const void* data_c64, const uint8_t* flag, const in
     for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
         int64_t nr = std::min<int64_t>(65535, rows - r0);
         grid.y = (unsigned)nr;
-        hipLaunchKernelGGL(k_pack, grid, dim3(256), 0, (hipStream_t)stream,
-                           (const float2*)data_c64 + (size_t)r0 * nchan * ncorr, flag + (size_t)r0 * nchan * ncorr,
-                           row_bl + r0, row_time + r0, (int)nchan, (int)ncorr, (int)nbl, (int)ntime,
-                           (float2*)vis_windows_c64, flag_windows);
+        const float2* dsl = (const float2*)data_c64 + (size_t)r0 * nchan * ncorr;
+        const uint8_t* fsl = flag + (size_t)r0 * nchan * ncorr;
+        // 1 / 2 / 4 correlations with 16-byte aligned rows: vector loads of a thread's (chan, corr) piece
+        const bool al = ((uintptr_t)data_c64 % 16 == 0) && ((uintptr_t)flag % 4 == 0);
+        if (ncorr == 4 && al)
+            hipLaunchKernelGGL(k_pack_v<4>, grid, dim3(256), 0, (hipStream_t)stream, dsl, fsl, row_bl + r0, row_time + r0,
+                               (int)nchan, (int)nbl, (int)ntime, (float2*)vis_windows_c64, flag_windows);
+        else if (ncorr == 2 && al)
+            hipLaunchKernelGGL(k_pack_v<2>, grid, dim3(256), 0, (hipStream_t)stream, dsl, fsl, row_bl + r0, row_time + r0,
+                               (int)nchan, (int)nbl, (int)ntime, (float2*)vis_windows_c64, flag_windows);
+        else if (ncorr == 1)
+            hipLaunchKernelGGL(k_pack_v<1>, grid, dim3(256), 0, (hipStream_t)stream, dsl, fsl, row_bl + r0, row_time + r0,
+                               (int)nchan, (int)nbl, (int)ntime, (float2*)vis_windows_c64, flag_windows);
+        else
+            hipLaunchKernelGGL(k_pack, grid, dim3(256), 0, (hipStream_t)stream, dsl, fsl,
+                               row_bl + r0, row_time + r0, (int)nchan, (int)ncorr, (int)nbl, (int)ntime,
+                               (float2*)vis_windows_c64, flag_windows);
         LAUNCHCHK();
     }
     return TRI_OK;
@@ -1317,8 +1330,20 @@ extern "C" int tri_unpack_data(const uint8_t* flag_windows, const int32_t* row_b
     for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
         int64_t nr = std::min<int64_t>(65535, rows - r0);
         grid.y = (unsigned)nr;
-        hipLaunchKernelGGL(k_unpack, grid, dim3(256), 0, (hipStream_t)stream, flag_windows, row_bl + r0, row_time + r0,
-                           (int)nchan, (int)ncorr, (int)nbl, (int)ntime, out_flags + (size_t)r0 * nchan * ncorr, any_corr);
+        uint8_t* osl = out_flags + (size_t)r0 * nchan * ncorr;
+        const bool al = (uintptr_t)out_flags % 4 == 0;
+        if (ncorr == 4 && al)
+            hipLaunchKernelGGL(k_unpack_v<4>, grid, dim3(256), 0, (hipStream_t)stream, flag_windows, row_bl + r0, row_time + r0,
+                               (int)nchan, (int)nbl, (int)ntime, osl, any_corr);
+        else if (ncorr == 2 && al)
+            hipLaunchKernelGGL(k_unpack_v<2>, grid, dim3(256), 0, (hipStream_t)stream, flag_windows, row_bl + r0, row_time + r0,
+                               (int)nchan, (int)nbl, (int)ntime, osl, any_corr);
+        else if (ncorr == 1)
+            hipLaunchKernelGGL(k_unpack_v<1>, grid, dim3(256), 0, (hipStream_t)stream, flag_windows, row_bl + r0, row_time + r0,
+                               (int)nchan, (int)nbl, (int)ntime, osl, any_corr);
+        else
+            hipLaunchKernelGGL(k_unpack, grid, dim3(256), 0, (hipStream_t)stream, flag_windows, row_bl + r0, row_time + r0,
+                               (int)nchan, (int)ncorr, (int)nbl, (int)ntime, osl, any_corr);
         LAUNCHCHK();
     }
     return TRI_OK;
