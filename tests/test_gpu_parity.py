@@ -526,8 +526,14 @@ def test_flag_dtypes_and_non_contiguous_inputs(gpu, oracle):
     e2 = oracle.sum_threshold_flagger(amp, flags, **kw)
     assert np.array_equal(gpu.sum_threshold_flagger(amp, flags, **kw), e2)
     assert np.array_equal(gpu.sum_threshold_flagger(amp.astype(np.float64), flags, **kw), e2)
+    # complex128 (the reference takes "real or complex" of either width, flagging.py:830-835): its float64
+    # amplitude, rounded once to float32 (flagging.py:856-859) -- equal to the complex64 result wherever the
+    # float64 hypot of the widened parts rounds to the float32 hypot, which holds for these samples
+    out128 = gpu.sum_threshold_flagger(vis.astype(np.complex128), flags, **kw)
+    amp64 = np.hypot(vis.real.astype(np.float64), vis.imag.astype(np.float64)).astype(np.float32)
+    assert np.array_equal(out128, oracle.sum_threshold_flagger(amp64, flags, **kw))
     with pytest.raises(TypeError):
-        gpu.sum_threshold_flagger(vis.astype(np.complex128), flags, **kw)
+        gpu.sum_threshold_flagger(vis.real.astype(np.int32), flags, **kw)
 
 
 def _random_case(rs):

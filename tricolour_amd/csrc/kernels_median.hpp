@@ -16,15 +16,30 @@
 // grid (R*G, W), block 256
 // ---------------------------------------------------------------------------
 #define SEL_CACHE 8
+// Wave-wide reductions on the DPP cross-lane paths (quad permutes, row mirrors, row broadcasts) instead of
+// six ds_bpermute round trips through the LDS crossbar: 6 moves (most fold into the ALU instruction) + a readlane.
+// Lanes outside a row broadcast's row mask keep the identity 0 (fine for unsigned max and sum).
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ unsigned wave_dpp0(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xF, false);
+}
 __device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += wave_dpp0<0xB1, 0xF>(v);      // quad_perm [1,0,3,2]
+    v += wave_dpp0<0x4E, 0xF>(v);      // quad_perm [2,3,0,1]
+    v += wave_dpp0<0x141, 0xF>(v);     // row_half_mirror
+    v += wave_dpp0<0x140, 0xF>(v);     // row_mirror: every lane of a row holds the row's sum
+    v += wave_dpp0<0x142, 0xA>(v);     // row_bcast:15 into rows 1 and 3
+    v += wave_dpp0<0x143, 0xC>(v);     // row_bcast:31 into rows 2 and 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor(v, o, 64));
-    return v;
+    v = max(v, wave_dpp0<0xB1, 0xF>(v));
+    v = max(v, wave_dpp0<0x4E, 0xF>(v));
+    v = max(v, wave_dpp0<0x141, 0xF>(v));
+    v = max(v, wave_dpp0<0x140, 0xF>(v));
+    v = max(v, wave_dpp0<0x142, 0xA>(v));
+    v = max(v, wave_dpp0<0x143, 0xC>(v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 #define SEL_BINS 2048
 // Three radix passes over the 31-bit key: digits of 11, 10 and 10 bits.  The
@@ -559,6 +574,7 @@ k_median_wave(const float* __restrict__ data, const uint8_t* __restrict__ flags,
     for (int u = 0; u < KS; u++)
         if (keys[u] != SENT) keys[u] -= kmin;
     unsigned prefix = 0, pmask = 0, kk = n >> 1;
+    bool single = false;
     unsigned* h = hist[wave];
     // Each wave owns its histogram and LDS operations of one wave execute in
     // order, so the passes need no workgroup barrier (the four segments of a
@@ -590,12 +606,12 @@ k_median_wave(const float* __restrict__ data, const uint8_t* __restrict__ flags,
             }
             unsigned exc = inc - sacc;
             bool mine = n > 0 && kk >= exc && kk < inc;
-            unsigned dsel = 0, cbase = exc;
+            unsigned dsel = 0, cbase = exc, csel = hv.x;
             if (mine) {
                 if (kk < exc + hv.x) dsel = 0;
-                else if (kk < exc + hv.x + hv.y) { dsel = 1; cbase = exc + hv.x; }
-                else if (kk < exc + hv.x + hv.y + hv.z) { dsel = 2; cbase = exc + hv.x + hv.y; }
-                else { dsel = 3; cbase = exc + hv.x + hv.y + hv.z; }
+                else if (kk < exc + hv.x + hv.y) { dsel = 1; cbase = exc + hv.x; csel = hv.y; }
+                else if (kk < exc + hv.x + hv.y + hv.z) { dsel = 2; cbase = exc + hv.x + hv.y; csel = hv.z; }
+                else { dsel = 3; cbase = exc + hv.x + hv.y + hv.z; csel = hv.w; }
             }
             unsigned long long bm = __ballot(mine);
             if (bm) {
@@ -604,10 +620,23 @@ k_median_wave(const float* __restrict__ data, const uint8_t* __restrict__ flags,
                 unsigned base = __shfl(cbase, src, 64);
                 prefix |= digit << shift;   // overlapping bits of a short last digit are already equal
                 kk -= base;
+                single = __shfl(csel, src, 64) == 1u;
             }
             pmask |= 0xFFu << shift;
         }
         wave_sync();
+        // the selected bucket holds one key: it is the median, no need to resolve its remaining digits
+        // (a segment of a few hundred samples usually gets here after two of its three or four passes)
+        if (single) break;
+    }
+    if (single) {
+        unsigned cand = 0;
+#pragma unroll
+        for (int u = 0; u < KS; u++) {
+            const unsigned k = keys[u];
+            if (k != SENT && (k & pmask) == prefix) cand = k;
+        }
+        prefix = wave_max_u32(cand);
     }
     unsigned cnt = 0, mx = 0;
 #pragma unroll
