@@ -302,7 +302,8 @@ int tri_sum_threshold_flagger_debug(const void *vis, int vis_dtype,
  * (HOST array) along each row; med is (n_win, rows, n_seg_ends - 1) float64,
  * NaN where a segment has no unflagged sample.  variant 0 = automatic,
  * 1 = wave kernel, 2 / 3 = three-pass workgroup kernel with scalar / vector loads,
- * 5 / 6 = two-pass workgroup kernel with vector / scalar loads.
+ * 5 / 6 = two-pass workgroup kernel with vector / scalar loads, 7 = two-pass
+ * kernel, vector loads over segments that need not be 4-aligned (row_len % 4 == 0).
  * Restates _median_abs / _median_abs_axis0 (flagging.py:267-304).
  */
 int tri_test_median(const float *data, const uint8_t *flags, double *med,

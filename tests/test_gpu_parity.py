@@ -226,7 +226,9 @@ def _np_median_abs(vals):
     (1, 300000, [0, 100000, 300000], (2, 3, 5, 6)),
     (2, 4096, [0, 4, 8, 2048, 4096], (5, 6)),
     (3, 40000, [0, 4000, 4004, 40000], (5, 6)),
-    (1, 6000, [0, 1, 2, 3001, 6000], (6,)),
+    (1, 6000, [0, 1, 2, 3001, 6000], (6, 7)),
+    (3, 40000, [0, 3999, 4001, 26214, 40000], (6, 7)),      # two-pass kernel, vector loads, segments that start / end inside a 16-byte group
+    (2, 8, [0, 1, 3, 8], (7,)),
 ])
 def test_median_kernels(gpu, rows, row_len, ends, variants):
     import ctypes as C
@@ -406,6 +408,34 @@ def test_full_size_shipped_kwargs_vs_oracle(gpu, oracle, name):
         report.append("out: %d of %d flags differ" % (bad, out.size))
     assert not report, "%s: %s" % (name, "; ".join(report))
     assert 0 < out.mean() < 1
+
+
+def test_two_stream_schedule_vs_oracle(gpu, oracle):
+    """TRI_SUBSTREAMS=1: the window set is split in two halves on two internal streams (the schedule SKA-sized
+    windows take by default); odd window counts, several batches per half, numpy and device inputs."""
+    import torch
+    rs = np.random.RandomState(77)
+    shape = (5, 1, 48, 160)
+    vis = (rs.standard_normal(shape) + 1j * rs.standard_normal(shape)).astype(np.complex64)
+    vis[..., 40] *= 8
+    vis[2, 0, 17] *= 5
+    flags = rs.uniform(size=shape) < 0.04
+    kw = dict(num_major_iterations=2, background_iterations=2)
+    exp = oracle.sum_threshold_flagger(vis, flags, **kw)
+    old = os.environ.get("TRI_SUBSTREAMS")
+    try:
+        os.environ["TRI_SUBSTREAMS"] = "1"
+        out = gpu.sum_threshold_flagger(vis, flags, **kw)
+        vd, fd = torch.from_numpy(vis).cuda(), torch.from_numpy(flags).cuda()
+        out_d = [gpu.sum_threshold_flagger(vd, fd, **kw) for _ in range(3)]     # back to back, unsynchronised
+        cnt = [int(o.sum().item()) for o in out_d]
+    finally:
+        if old is None:
+            os.environ.pop("TRI_SUBSTREAMS", None)
+        else:
+            os.environ["TRI_SUBSTREAMS"] = old
+    assert np.array_equal(out, exp)
+    assert all(np.array_equal(o.cpu().numpy(), exp) for o in out_d) and cnt == [int(exp.sum())] * 3
 
 
 def test_size_independent_properties_at_slab_scale(gpu):

@@ -144,6 +144,10 @@ __host__ __device__ constexpr int boxr_waves(int ks) { return ks <= 16 ? BOXR_WA
 #ifndef BOXR_WAVES_F32
 #define BOXR_WAVES_F32 2
 #endif
+#ifndef BOXF_PF_SMALL
+#define BOXF_PF_SMALL 16
+#endif
+__host__ __device__ constexpr int boxr_pf_f(int ks) { return ks <= 16 ? BOXF_PF_SMALL : boxr_pf(ks); }
 __host__ __device__ constexpr int boxr_waves_f(int ks) { return ks < 32 ? 2 : (ks == 32 ? BOXR_WAVES_F32 : 1); }
 __host__ __device__ constexpr int boxr_lcm(int a, int b) {
     int x = a, y = b;
@@ -151,16 +155,16 @@ __host__ __device__ constexpr int boxr_lcm(int a, int b) {
     return a / x * b;
 }
 
-// grid (ceil(C / 64), W), block 64, dynamic LDS 4 * d * 64 floats; IMG 0: weight image
-// (0/1 input, int32 cascade), IMG 1: data image (flagged samples zeroed, float64 cascade)
-template <int KS, bool HASL, int IMG>
-__global__ void __launch_bounds__(64, boxr_waves(KS))
-k_boxt(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags,
-       float* __restrict__ dstImg, int n, int C, int r, float denom, size_t sws, size_t dws) {
+// IMG 0: weight image (0/1 input, int32 cascade), IMG 1: data image (flagged samples zeroed, float64
+// cascade).  PACKED: flags as TF4 words [n / 4][C] (the 2-D path); else one byte per sample [n][C]
+// (the spectrum path: lines = channels of the median spectra, columns = windows of the batch).
+template <int KS, bool HASL, int IMG, bool PACKED, int PF>
+__device__ __forceinline__ void boxt_body(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags,
+                                          float* __restrict__ dstImg, int n, int C, int r, float denom, size_t sws, size_t dws,
+                                          const size_t win) {
     extern __shared__ float cf_ring[];
     const int c = blockIdx.x * 64 + threadIdx.x;
     if (c >= C) return;                                  // no workgroup barrier in this kernel
-    const size_t win = blockIdx.y;
     constexpr int BT = 64;
     const int R2x = 2 * r;
     const int d = R2x - KS;                              // LDS slots per stage (host: even, >= 2 when HASL, else 0)
@@ -170,7 +174,7 @@ k_boxt(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags,
     const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(srcData + win * sws), 0, (int)((unsigned)n * rowb), 0x00020000);
     const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(srcFlags + win * sws), 0, (int)((unsigned)(n / 4) * rowb), 0x00020000);
+        (void*)(srcFlags + win * sws), 0, PACKED ? (int)((unsigned)(n / 4) * rowb) : (int)((unsigned)n * (unsigned)C), 0x00020000);
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(dstImg + win * dws), 0, (int)((unsigned)n * rowb), 0x00020000);
     const int coff = c * 4;
@@ -178,7 +182,6 @@ k_boxt(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags,
     if (HASL)
         for (int k = 0; k < 4 * d; k++) ring[(size_t)k * BT] = 0.0f;
     const int total = n + 4 * r + 3;
-    constexpr int PF = boxr_pf(KS);
     constexpr int UNR = boxr_lcm(KS, PF);
     constexpr bool SPLIT = KS <= 32;                     // separate predicate-free interior body
 
@@ -190,13 +193,22 @@ k_boxt(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags,
     constexpr size_t BT4 = (size_t)4 * BT;
     int lslot = 0;
     float pre[PF];
-    unsigned prew[PF / 4];
+    unsigned prew[PACKED ? PF / 4 : PF];                 // packed: one word per four positions; else one byte each
     auto issue = [&](int t0) {
+        if (PACKED) {
 #pragma unroll
-        for (int q = 0; q < PF / 4; q++) {
-            const int t = t0 + 4 * q;                    // (the scalar row offset is not range-checked: clamp it)
-            const unsigned w = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(frs, coff, t < n ? (int)((unsigned)(t >> 2) * rowb) : 0, 0);
-            prew[q] = (t < n) ? w : 0x01010101u;         // beyond the line end: flagged (weight 0, data ignored)
+            for (int q = 0; q < PF / 4; q++) {
+                const int t = t0 + 4 * q;                // (the scalar row offset is not range-checked: clamp it)
+                const unsigned w = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(frs, coff, t < n ? (int)((unsigned)(t >> 2) * rowb) : 0, 0);
+                prew[q] = (t < n) ? w : 0x01010101u;     // beyond the line end: flagged (weight 0, data ignored)
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < PF; u++) {
+                const int t = t0 + u;
+                const unsigned w = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(frs, c, t < n ? (int)((unsigned)t * (unsigned)C) : 0, 0);
+                prew[PACKED ? 0 : u] = (t < n) ? w : 1u;
+            }
         }
         if (IMG == 1) {
 #pragma unroll
@@ -216,7 +228,7 @@ k_boxt(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags,
                 V cur[PF];
 #pragma unroll
                 for (int u = 0; u < PF; u++) {
-                    const bool fl = ((prew[u >> 2] >> (8 * (u & 3))) & 0xFFu) != 0;
+                    const bool fl = PACKED ? ((prew[u >> 2] >> (8 * (u & 3))) & 0xFFu) != 0 : prew[PACKED ? 0 : u] != 0;
                     cur[u] = (IMG == 0) ? (fl ? (V)0 : (V)1) : (fl ? (V)0 : (V)pre[u]);
                 }
                 issue(m0 + PF);
@@ -248,6 +260,27 @@ k_boxt(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags,
     }
 }
 
+// grid (ceil(C / 64), W), block 64, dynamic LDS 4 * d * 64 floats: one image per launch (2-D path)
+template <int KS, bool HASL, int IMG>
+__global__ void __launch_bounds__(64, boxr_waves(KS))
+k_boxt(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags,
+       float* __restrict__ dstImg, int n, int C, int r, float denom, size_t sws, size_t dws) {
+    boxt_body<KS, HASL, IMG, true, boxr_pf(KS)>(srcData, srcFlags, dstImg, n, C, r, denom, sws, dws, blockIdx.y);
+}
+
+// Spectrum path: byte flags, both images in one launch (blockIdx.y = image): the lines are as long as the
+// window has channels but there are only as many as the batch has windows, so what counts is the time per
+// step of a lone wave -- no LDS round trip in the recurrence.  grid (ceil(C / 64), 2), block 64
+// a lone wave hides HBM latency only through its own loads in flight: prefetch as deep as the registers allow
+__host__ __device__ constexpr int boxt_spec_pf(int ks) { return ks <= 16 ? 64 : (ks == 32 ? 32 : 16); }
+template <int KS, bool HASL>
+__global__ void __launch_bounds__(64, 1)
+k_boxt_spec(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags,
+            float* __restrict__ dstW, float* __restrict__ dstO, int n, int C, int r, float denom) {
+    if (blockIdx.y == 0) boxt_body<KS, HASL, 0, false, boxt_spec_pf(KS)>(srcData, srcFlags, dstW, n, C, r, denom, 0, 0, 0);
+    else boxt_body<KS, HASL, 1, false, boxt_spec_pf(KS)>(srcData, srcFlags, dstO, n, C, r, denom, 0, 0, 0);
+}
+
 // ---- frequency-axis stage fused with the masked division ---------------------------
 // Input images stored transposed: line c is row c of a [C][ld] array (the time-axis
 // stage's TF output; the data image img_gap elements after the weight image), staged PF
@@ -271,7 +304,7 @@ k_boxf(const float* __restrict__ srcW, unsigned img_gap,
        int n, int C, int ld, int r, BoxDenom denom, size_t sws_img, size_t dws, size_t ws_data,
        uint8_t* __restrict__ nanflag) {
     extern __shared__ float cf_ring[];
-    constexpr int PF = boxr_pf(KS);
+    constexpr int PF = boxr_pf_f(KS);
     constexpr int UNR = boxr_lcm(KS, PF);
     constexpr int BT = 64;
     constexpr int LPI = 32 / PF;                               // lines covered by one staging load instruction (per image)

@@ -182,22 +182,33 @@ __global__ void k_colinterp(float* __restrict__ a, int L, int C, size_t ws,
     int last = -1;       // index of the last valid sample
     float lastv = 0.0f;
     int run = 0;         // start of the current NaN run
-    for (int i = 0; i < L; i++) {
-        float v = x[(size_t)i * Cs];
-        if (isnan(v)) continue;
-        if (run < i) {
-            if (last < 0) {
-                for (int j = run; j < i; j++) x[(size_t)j * Cs] = v;  // extrapolate backwards
-            } else {
-                float diff = v - lastv;
-                double grad = (double)diff / (double)(i - last);
-                for (int j = run; j < i; j++)
-                    x[(size_t)j * Cs] = (float)((double)lastv + (double)(j - last) * grad);
+    // The scan is sequential, but the samples AHEAD of it are never rewritten (repairs only touch
+    // positions behind the scan): read them 64 at a time, so that a line costs L / 64 memory
+    // round trips instead of L (SKA-sized windows have 65536-long lines on a few thousand threads).
+    constexpr int PFI = 64;
+    for (int i0 = 0; i0 < L; i0 += PFI) {
+        float vv[PFI];
+#pragma unroll
+        for (int u = 0; u < PFI; u++) vv[u] = (i0 + u < L) ? x[(size_t)(i0 + u) * Cs] : NAN;
+#pragma unroll
+        for (int u = 0; u < PFI; u++) {
+            const int i = i0 + u;
+            const float v = vv[u];
+            if (i >= L || isnan(v)) continue;
+            if (run < i) {
+                if (last < 0) {
+                    for (int j = run; j < i; j++) x[(size_t)j * Cs] = v;  // extrapolate backwards
+                } else {
+                    float diff = v - lastv;
+                    double grad = (double)diff / (double)(i - last);
+                    for (int j = run; j < i; j++)
+                        x[(size_t)j * Cs] = (float)((double)lastv + (double)(j - last) * grad);
+                }
             }
+            last = i;
+            lastv = v;
+            run = i + 1;
         }
-        last = i;
-        lastv = v;
-        run = i + 1;
     }
     if (run < L) {
         float fill = last < 0 ? 0.0f : lastv;  // all NaN -> zeros; else extrapolate forwards
@@ -207,7 +218,15 @@ __global__ void k_colinterp(float* __restrict__ a, int L, int C, size_t ws,
     if (resid) {
         const float* d = data + (size_t)blockIdx.y * ws_data + c;
         float* rr = resid + (size_t)blockIdx.y * ws + c;
-        for (int j = 0; j < L; j++) rr[(size_t)j * Cs] = d[(size_t)j * Cs] - x[(size_t)j * Cs];
+        int j = 0;
+        for (; j + PFI <= L; j += PFI) {
+            float dv[PFI], xv[PFI];
+#pragma unroll
+            for (int u = 0; u < PFI; u++) { dv[u] = d[(size_t)(j + u) * Cs]; xv[u] = x[(size_t)(j + u) * Cs]; }
+#pragma unroll
+            for (int u = 0; u < PFI; u++) rr[(size_t)(j + u) * Cs] = dv[u] - xv[u];
+        }
+        for (; j < L; j++) rr[(size_t)j * Cs] = d[(size_t)j * Cs] - x[(size_t)j * Cs];
     }
 }
 

@@ -202,7 +202,8 @@ k_median(const float* __restrict__ data, const uint8_t* __restrict__ flags,
 // Any monotone map selects exactly; the sample only decides how well the bins resolve.
 // If the rank falls into a catch-all end bin or the bin overflows the LDS list, the
 // workgroup runs the three-pass select on the whole segment instead.
-// grid (R*G, W), block 256; VEC as k_median
+// grid (R*G, W), block 256; VEC: contiguous segments of 16-byte aligned rows (row length % 4 == 0; the
+// segments themselves may start and end anywhere)
 // ---------------------------------------------------------------------------
 #define SEL2_CAND 4096
 #ifndef MED2_UNROLL
@@ -320,17 +321,32 @@ k_median2(const float* __restrict__ data, const uint8_t* __restrict__ flags,
     data += win * WSd + rel;
     flags += win * WSf + rel;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mis = VEC ? (int)(seg_start[g] & 3) : 0;           // VEC: rows are 16-byte aligned, segments need not be
 
     // every unflagged key of the segment, in this thread's share
     auto enumerate_all = [&](auto&& visit) {
         if (VEC) {
-            const float4* d4 = reinterpret_cast<const float4*>(data);
-            const uchar4* f4 = reinterpret_cast<const uchar4*>(flags);
-            const int64_t n4 = len / 4;
+            // 16-byte groups of the (16-byte aligned) row that cover the segment; a segment may start and
+            // end inside a group (mis = its offset in the first one): only the first and last group are masked
+            const float4* d4 = reinterpret_cast<const float4*>(data - mis);
+            const uchar4* f4 = reinterpret_cast<const uchar4*>(flags - mis);
+            const int64_t n4 = (len + mis + 3) / 4;
+            auto edge = [&](int64_t i) {
+                const float4 dv = d4[i];
+                const uchar4 fv = f4[i];
+                const int64_t j = 4 * i - mis;
+                if (j >= 0 && j < len && !fv.x) visit(__float_as_uint(dv.x) & 0x7FFFFFFFu);
+                if (j + 1 >= 0 && j + 1 < len && !fv.y) visit(__float_as_uint(dv.y) & 0x7FFFFFFFu);
+                if (j + 2 >= 0 && j + 2 < len && !fv.z) visit(__float_as_uint(dv.z) & 0x7FFFFFFFu);
+                if (j + 3 >= 0 && j + 3 < len && !fv.w) visit(__float_as_uint(dv.w) & 0x7FFFFFFFu);
+            };
+            if (tid == 0 && n4 > 0) edge(0);
+            if (tid == 1 && n4 > 1) edge(n4 - 1);
             // MED2_UNROLL 16-byte groups in flight per thread: the segment streams from HBM once
             // (pass 1) and from L2 / Infinity Cache afterwards
-            int64_t i = tid;
-            for (; i + 256 * (MED2_UNROLL - 1) < n4; i += 256 * MED2_UNROLL) {
+            const int64_t hi4 = n4 - 1;                          // interior groups: [1, n4 - 1)
+            int64_t i = 1 + tid;
+            for (; i + 256 * (MED2_UNROLL - 1) < hi4; i += 256 * MED2_UNROLL) {
                 float4 dv[MED2_UNROLL];
                 uchar4 fv[MED2_UNROLL];
 #pragma unroll
@@ -343,7 +359,7 @@ k_median2(const float* __restrict__ data, const uint8_t* __restrict__ flags,
                     if (!fv[q].w) visit(__float_as_uint(dv[q].w) & 0x7FFFFFFFu);
                 }
             }
-            for (; i < n4; i += 256) {
+            for (; i < hi4; i += 256) {
                 float4 dv = d4[i];
                 uchar4 fv = f4[i];
                 if (!fv.x) visit(__float_as_uint(dv.x) & 0x7FFFFFFFu);

@@ -149,6 +149,8 @@ struct Ws {
     // spectrum layout [Fa][Wb]
     float *sdata, *sw, *so, *sres;
     uint8_t *sflags, *sbgf, *sout, *srows;   // srows: sout as rows [Wb][Fa]
+    float* srowsf;                           // spectrum residuals as rows [Wb][Fa] (median input)
+    uint8_t* srowsu;                         // their flags as rows
     double* smed;     // [Wb][G]
     // SumThreshold scratch
     double* ring;
@@ -207,6 +209,8 @@ static void carve(const Plan& pl, int64_t Wb, void* base, size_t cap, bool dry, 
     ws->sbgf = b.get<uint8_t>(Fa * W);
     ws->sout = b.get<uint8_t>(Fa * W);
     ws->srows = b.get<uint8_t>(Fa * W);
+    ws->srowsf = b.get<float>(Fa * W);
+    ws->srowsu = b.get<uint8_t>(Fa * W);
     ws->smed = b.get<double>(W * G);
     // SumThreshold scratch: one slot set per (window, chunk, column) thread
     size_t thrT = W * Fa, thrF = W * T * G;
@@ -399,7 +403,7 @@ int launch_median(const Run& r, const float* data, const uint8_t* flags, double*
             hipLaunchKernelGGL(k_median<true>, grid, dim3(256), 0, r.st, data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
         else if (three)
             hipLaunchKernelGGL(k_median<false>, grid, dim3(256), 0, r.st, data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
-        else if (vec_ok)
+        else if (vec_ok || row4)
             hipLaunchKernelGGL(k_median2<true>, grid, dim3(256), 0, r.st, data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
         else
             hipLaunchKernelGGL(k_median2<false>, grid, dim3(256), 0, r.st, data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
@@ -509,6 +513,34 @@ int launch_boxt_ks(const Run& r, const float* srcData, const uint8_t* srcFlags, 
     return TRI_OK;
 }
 
+// Spectrum path (byte flags [n][C], a single "window", both images in one launch)
+template <int KS>
+int launch_boxt_spec_ks(const Run& r, const float* srcData, const uint8_t* srcFlags, float* dstW, float* dstO,
+                        int n, int C, int rad, float denom) {
+    const int d = 2 * rad - KS;
+    const size_t lds = (size_t)4 * d * 64 * sizeof(float);
+    dim3 grid((unsigned)cdiv(C, 64), 2);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boxt_spec<KS, true>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    HIPCHK(attr);
+    if (d > 0) hipLaunchKernelGGL((k_boxt_spec<KS, true>), grid, dim3(64), lds, r.st, srcData, srcFlags, dstW, dstO, n, C, rad, denom);
+    else hipLaunchKernelGGL((k_boxt_spec<KS, false>), grid, dim3(64), 0, r.st, srcData, srcFlags, dstW, dstO, n, C, rad, denom);
+    LAUNCHCHK();
+    return TRI_OK;
+}
+
+int launch_boxt_spec(const Run& r, int ks, const float* srcData, const uint8_t* srcFlags, float* dstW, float* dstO,
+                     int n, int C, int rad, float denom) {
+    switch (ks) {
+        case 8: return launch_boxt_spec_ks<8>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom);
+        case 16: return launch_boxt_spec_ks<16>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom);
+        case 32: return launch_boxt_spec_ks<32>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom);
+        case 64: return launch_boxt_spec_ks<64>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom);
+        case 80: return launch_boxt_spec_ks<80>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom);
+    }
+    return set_err(TRI_EINVAL, "no register-ring kernel for %d slots", ks);
+}
+
 int launch_boxt(const Run& r, int ks, const float* srcData, const uint8_t* srcFlags, float* dstW, float* dstO,
                 int n, int C, int rad, float denom, size_t sws, size_t dws, int64_t W) {
     switch (ks) {
@@ -528,6 +560,10 @@ int launch_colfilter(const Run& r, int srcmode, float* bufW, float* bufO, const 
     const int intw = (weights_are_01 && rad <= 31) ? 1 : 0;
     int bt = colfilter_lds_block(rad, C);
     if (deferred_denom) *deferred_denom = 0.0f;
+    // spectrum path (one "window" of byte flags + data, both images): register-ring kernel from r = 4 on
+    if (srcmode == 0 && !deferred_denom && !transposed_out && weights_are_01 && W == 1 && boxr_pick_ks(rad) > 0 &&
+        (uint64_t)n * (uint64_t)C * 4u < (1ull << 31))
+        return launch_boxt_spec(r, boxr_pick_ks(rad), srcData, srcFlags, dstW, dstO, n, C, rad, denom);
     if (srcmode == 2 && !deferred_denom && !transposed_out && weights_are_01 && boxr_pick_ks_t(rad) > 0 &&
         n % 4 == 0 && (uint64_t)n * (uint64_t)C * 4u < (1ull << 31))   // signed 32-bit buffer offsets
         return launch_boxt(r, boxr_pick_ks_t(rad), srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
@@ -765,7 +801,7 @@ int launch_boxf_ks(const Run& r, const float* srcW, const float* srcO, float* ds
                    int n, int C, int ld, int rad, size_t sws_img, size_t dws, size_t ws_data, int64_t W, uint8_t* nanflag) {
     const BoxDenom denom = box_reciprocal(box_denominator(rad));
     const int d = 2 * rad - KS;
-    const size_t lds = ((size_t)4 * d * 64 + (size_t)2 * boxr_pf(KS) * BOXF_TS) * sizeof(float);
+    const size_t lds = ((size_t)4 * d * 64 + (size_t)2 * boxr_pf_f(KS) * BOXF_TS) * sizeof(float);
     // one descriptor per window spans both images: the data image must follow the weight image closely
     if (srcO <= srcW || ((uint64_t)(srcO - srcW) + (uint64_t)C * ld) * 4u >= (1ull << 31))
         return set_err(TRI_EUNSUPPORTED, "fused frequency stage: the data image must follow the weight image within 2^31 bytes");
@@ -829,6 +865,23 @@ int launch_colfilter_t4(const Run& r, const float* srcW, const float* srcO, floa
 // _get_background2d (flagging.py:516-579) for the median spectra of the batch,
 // held in spectrum layout [Fa][Wb] (line axis = channel, column = window).
 // Result: rows [0,Fa) of ws.so hold the background.
+// Per (window, chunk) medians of a spectrum-layout image [Fa][Wb]: the segments run along the slow axis there
+// (stride Wb floats), so the image and its flags are first turned into rows [Wb][Fa] (a few MB) and the
+// segments become contiguous.  Output smed[w][g].
+int spectrum_medians(const Run& r, const float* img, const uint8_t* flg) {
+    const Plan& pl = r.pl;
+    const Ws& ws = r.ws;
+    const int Fa = (int)pl.Fa, Wn = (int)r.Wb, G = (int)pl.G;
+    int rc = launch_transpose<float>(r, img, ws.srowsf, Fa, Wn, 0, 0, 1);
+    if (rc) return rc;
+    rc = launch_transpose<uint8_t>(r, flg, ws.srowsu, Fa, Wn, 0, 0, 1);
+    if (rc) return rc;
+    bool seg4 = Fa % 4 == 0;
+    for (int64_t g = 0; g < pl.G + 1 && seg4; g++) seg4 = r.p->chunk_ends[g] % 4 == 0;
+    return launch_median(r, ws.srowsf, ws.srowsu, ws.smed, 0, 0, (size_t)Fa, 1, ws.segC_start, ws.segC_len, Wn, G, 1, pl.maxchunk,
+                         seg4, Fa % 4 == 0, seg4);
+}
+
 int spectrum_background(const Run& r) {
     const Plan& pl = r.pl;
     const Ws& ws = r.ws;
@@ -854,7 +907,7 @@ int spectrum_background(const Run& r) {
             { int rc2 = launch_masked_div<1>(r, ws.sw, ws.so, ws.sdata, nS, 0, 0, 1); if (rc2) return rc2; }
             // per (window, chunk) median of the residual: element (f, w) at f*Wn + w
             // -> row = w (RS 1), element stride Wn
-            int rc = launch_median(r, ws.so, ws.sbgf, ws.smed, 0, 0, 1, (size_t)Wn, ws.segC_start, ws.segC_len, Wn, G, 1, pl.maxchunk);
+            int rc = spectrum_medians(r, ws.so, ws.sbgf);
             if (rc) return rc;
             hipLaunchKernelGGL(k_reject<false>, grid1(nS, 1), dim3(256), 0, r.st, ws.so, ws.sbgf, ws.smed, ws.d_chunk_of, rej, Fa, Wn, G, (size_t)0, (size_t)0);
             LAUNCHCHK();
@@ -1066,7 +1119,7 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
     size_t nS = (size_t)Fa * Wn;
     rc = launch_sub(r, ws.sdata, ws.so, ws.sres, nS, 0, 0, 0, 1);
     if (rc) return rc;
-    rc = launch_median(r, ws.sres, ws.sflags, ws.smed, 0, 0, 1, (size_t)Wn, ws.segC_start, ws.segC_len, Wn, G, 1, pl.maxchunk);
+    rc = spectrum_medians(r, ws.sres, ws.sflags);
     if (rc) return rc;
     rc = launch_colst(r, pl.swF, ws.sres, ws.smed, ws.sout, ws.d_chunk_ends, Fa, Wn, G, 0, 0, 1);
     if (rc) return rc;
@@ -1164,37 +1217,23 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
     return TRI_OK;
 }
 
-int flagger_impl(const void* vis, int vis_dtype, const uint8_t* flags, uint8_t* out_flags,
-                 int64_t n_cp, int64_t T, int64_t F, const tri_params* p, void* workspace,
-                 size_t workspace_bytes, void* stream, Debug* dbg) {
-    if (!vis || !flags || !out_flags || !p) return set_err(TRI_EINVAL, "NULL pointer argument");
-    if (n_cp < 0) return set_err(TRI_EINVAL, "negative window count");
-    if (vis_dtype != TRI_VIS_C64 && vis_dtype != TRI_VIS_F32) return set_err(TRI_EUNSUPPORTED, "vis dtype must be complex64 or float32");
-    Run r;
-    r.st = (hipStream_t)stream;
-    r.p = p;
-    r.dbg = dbg;
-    int rc = make_plan(T, F, p, &r.pl);
-    if (rc) return rc;
-    if (r.pl.G > TRI_MAX_CHUNKS) return set_err(TRI_EUNSUPPORTED, "at most %d frequency chunks", TRI_MAX_CHUNKS);
-    // the 16-byte kernels need 16-byte aligned user buffers (torch allocations are)
-    if ((((uintptr_t)vis) | ((uintptr_t)flags) | ((uintptr_t)out_flags)) & 15) r.pl.vec = false;
-    if (n_cp == 0) return TRI_OK;
-    if (!workspace) return set_err(TRI_EWORKSPACE, "NULL workspace");
-    if (((uintptr_t)workspace & 255) != 0) return set_err(TRI_EINVAL, "workspace must be 256-byte aligned");
-    // largest batch the workspace admits (the carve-up is monotone in Wb)
+// All batches of the windows [w_begin, w_end) on r.st with the workspace [wsp, wsp + ws_bytes).
+int process_windows(Run& r, const void* vis, int vis_dtype, const uint8_t* flags, uint8_t* out_flags,
+                    int64_t w_begin, int64_t w_end, int64_t T, int64_t F, void* wsp, size_t ws_bytes, bool tap_first) {
+    const tri_params* p = r.p;
     Ws probe;
     carve(r.pl, 1, nullptr, 0, true, &probe);
-    if (probe.total > workspace_bytes)
-        return set_err(TRI_EWORKSPACE, "workspace of %zu bytes is smaller than the %zu needed for one window", workspace_bytes, probe.total);
-    int64_t lo = 1, hi = std::min<int64_t>(n_cp, 16384);
+    if (probe.total > ws_bytes)
+        return set_err(TRI_EWORKSPACE, "workspace of %zu bytes is smaller than the %zu needed for one window", ws_bytes, probe.total);
+    // largest batch the workspace admits (the carve-up is monotone in Wb)
+    int64_t lo = 1, hi = std::min<int64_t>(w_end - w_begin, 16384);
     while (lo < hi) {
         int64_t mid = (lo + hi + 1) / 2;
         carve(r.pl, mid, nullptr, 0, true, &probe);
-        if (probe.total <= workspace_bytes) lo = mid; else hi = mid - 1;
+        if (probe.total <= ws_bytes) lo = mid; else hi = mid - 1;
     }
-    int64_t Wb = lo;
-    carve(r.pl, Wb, workspace, workspace_bytes, false, &r.ws);
+    const int64_t Wb = lo;
+    carve(r.pl, Wb, wsp, ws_bytes, false, &r.ws);
 
     // device tables
     ChunkTab ct;
@@ -1207,15 +1246,13 @@ int flagger_impl(const void* vis, int vis_dtype, const uint8_t* flags, uint8_t* 
                            r.ws.segB_len, r.ws.segT_start, r.ws.segT_len, r.ws.d_chunk_of);
         LAUNCHCHK();
     }
-    size_t NF = (size_t)T * F;
-    size_t esz = vis_dtype == TRI_VIS_C64 ? 8 : 4;
-    if (p->num_major_iterations == 0)
-        HIPCHK(hipMemsetAsync(out_flags, 0, (size_t)n_cp * NF, r.st));
-    for (int64_t w0 = 0; w0 < n_cp; w0 += Wb) {
-        r.Wb = std::min(Wb, n_cp - w0);
+    const size_t NF = (size_t)T * F;
+    const size_t esz = vis_dtype == TRI_VIS_C64 ? 8 : 4;
+    int rc = TRI_OK;
+    for (int64_t w0 = w_begin; w0 < w_end; w0 += Wb) {
+        r.Wb = std::min(Wb, w_end - w0);
         const char* vis_b = (const char*)vis + (size_t)w0 * NF * esz;
         uint8_t* out_b = out_flags + (size_t)w0 * NF;
-        size_t nb = (size_t)r.Wb * NF;
         // flagging.py:1182  iter_flags = flags.copy()  (non-zero = flagged)
         rc = launch_u8<2>(r, flags + (size_t)w0 * NF, r.ws.iter, NF, NF, NF, r.Wb);
         if (rc) return rc;
@@ -1235,13 +1272,98 @@ int flagger_impl(const void* vis, int vis_dtype, const uint8_t* flags, uint8_t* 
         }
         for (int64_t it = 0; it < p->num_major_iterations; it++) {
             bool last = it == p->num_major_iterations - 1;
-            bool tap = last && w0 == 0;
+            bool tap = last && tap_first && w0 == w_begin;
             if (vis_dtype == TRI_VIS_C64) rc = run_iteration<TRI_VIS_C64>(r, vis_b, r.ws.iter, out_b, !last, tap);
             else rc = run_iteration<TRI_VIS_F32>(r, vis_b, r.ws.iter, out_b, !last, tap);
             if (rc) return rc;
         }
     }
     return TRI_OK;
+}
+
+// Optional schedule (TRI_SUBSTREAMS=1): two internal streams per calling thread (created once).  A window set
+// whose 1-D spectrum path is a long sequential recurrence on a handful of lanes (SKA-sized windows:
+// 65536-channel lines, one lane per window) is split in two halves that run concurrently -- the high-priority
+// half at full speed, the other one in the gaps its spectrum kernels leave on the device.
+struct SubStreams {
+    hipStream_t st[2] = {nullptr, nullptr};
+    hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
+    int device = -1;
+};
+thread_local SubStreams g_sub;
+
+int get_substreams(SubStreams** out) {
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    if (g_sub.device != dev) {
+        if (g_sub.device >= 0) return set_err(TRI_EUNSUPPORTED, "a calling thread must stay on one device");
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));    // lo = least, hi = greatest priority (numerically lower)
+        HIPCHK(hipStreamCreateWithPriority(&g_sub.st[0], hipStreamNonBlocking, hi));
+        HIPCHK(hipStreamCreateWithPriority(&g_sub.st[1], hipStreamNonBlocking, lo));
+        HIPCHK(hipEventCreateWithFlags(&g_sub.fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&g_sub.join[0], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&g_sub.join[1], hipEventDisableTiming));
+        g_sub.device = dev;
+    }
+    *out = &g_sub;
+    return TRI_OK;
+}
+
+int flagger_impl(const void* vis, int vis_dtype, const uint8_t* flags, uint8_t* out_flags,
+                 int64_t n_cp, int64_t T, int64_t F, const tri_params* p, void* workspace,
+                 size_t workspace_bytes, void* stream, Debug* dbg) {
+    if (!vis || !flags || !out_flags || !p) return set_err(TRI_EINVAL, "NULL pointer argument");
+    if (n_cp < 0) return set_err(TRI_EINVAL, "negative window count");
+    if (vis_dtype != TRI_VIS_C64 && vis_dtype != TRI_VIS_F32) return set_err(TRI_EUNSUPPORTED, "vis dtype must be complex64 or float32");
+    Run r;
+    r.st = (hipStream_t)stream;
+    r.p = p;
+    r.dbg = dbg;
+    int rc = make_plan(T, F, p, &r.pl);
+    if (rc) return rc;
+    if (r.pl.G > TRI_MAX_CHUNKS) return set_err(TRI_EUNSUPPORTED, "at most %d frequency chunks", TRI_MAX_CHUNKS);
+    // the 16-byte kernels need 16-byte aligned user buffers (torch allocations are)
+    if ((((uintptr_t)vis) | ((uintptr_t)flags) | ((uintptr_t)out_flags)) & 15) r.pl.vec = false;
+    if (n_cp == 0) return TRI_OK;
+    if (!workspace) return set_err(TRI_EWORKSPACE, "NULL workspace");
+    if (((uintptr_t)workspace & 255) != 0) return set_err(TRI_EINVAL, "workspace must be 256-byte aligned");
+    if (p->num_major_iterations == 0)
+        HIPCHK(hipMemsetAsync(out_flags, 0, (size_t)n_cp * (size_t)T * F, r.st));
+
+    // TRI_SUBSTREAMS=0 / 1 forces the single-stream / two-stream schedule
+    const char* fe = getenv("TRI_SUBSTREAMS");      // read per call: tests toggle it
+    const int force = fe ? atoi(fe) : -1;
+    Ws probe;
+    carve(r.pl, 1, nullptr, 0, true, &probe);
+    const size_t half = (workspace_bytes / 2) & ~(size_t)255;
+    const bool can_split = n_cp >= 2 && half >= probe.total && dbg == nullptr;
+    // (off by default: on slabs of 64 SKA-sized windows the halves lose more parallelism in the 2-D kernels --
+    //  512 lines per window on the frequency axis -- than the overlap of the spectrum kernels returns:
+    //  1.5 against 2.5 Gvis/s, profiles/r02_bench_ska.log)
+    const bool want_split = force == 1;
+    if (!(can_split && want_split))
+        return process_windows(r, vis, vis_dtype, flags, out_flags, 0, n_cp, T, F, workspace, workspace_bytes, true);
+
+    SubStreams* ss = nullptr;
+    rc = get_substreams(&ss);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(ss->fork, r.st));
+    const int64_t mid = (n_cp + 1) / 2;
+    for (int k = 0; k < 2 && rc == TRI_OK; k++) {
+        Run rk;
+        rk.st = ss->st[k];
+        rk.p = p;
+        rk.dbg = nullptr;
+        rk.pl = r.pl;
+        HIPCHK(hipStreamWaitEvent(rk.st, ss->fork, 0));
+        rc = process_windows(rk, vis, vis_dtype, flags, out_flags, k == 0 ? 0 : mid, k == 0 ? mid : n_cp, T, F,
+                             (char*)workspace + (size_t)k * half, half, false);
+        // join even after an error: the caller's stream must not run ahead of work already queued
+        (void)hipEventRecord(ss->join[k], rk.st);
+        (void)hipStreamWaitEvent(r.st, ss->join[k], 0);
+    }
+    return rc;
 }
 
 }  // namespace
@@ -1551,7 +1673,11 @@ extern "C" int tri_test_median(const float* data, const uint8_t* flags, double* 
     else if (variant == 5)
         hipLaunchKernelGGL(k_median2<true>, dim3((unsigned)(R * G), (unsigned)n_win), dim3(256), 0, st, data, flags,
                            med, WS, WS, RS, (size_t)1, d_start, d_len, R, G);
-    else if (variant == 6)
+    else if (variant == 7) {
+        if (row_len % 4 != 0) return set_err(TRI_EINVAL, "variant 7 needs row_len % 4 == 0");
+        hipLaunchKernelGGL(k_median2<true>, dim3((unsigned)(R * G), (unsigned)n_win), dim3(256), 0, st, data, flags,
+                           med, WS, WS, RS, (size_t)1, d_start, d_len, R, G);
+    } else if (variant == 6)
         hipLaunchKernelGGL(k_median2<false>, dim3((unsigned)(R * G), (unsigned)n_win), dim3(256), 0, st, data, flags,
                            med, WS, WS, RS, (size_t)1, d_start, d_len, R, G);
     else
