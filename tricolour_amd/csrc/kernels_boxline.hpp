@@ -297,8 +297,8 @@ k_boxt_spec(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFl
 // outputs below 2^31 bytes per window).
 // grid (ceil(C / 32), W), block 64, dynamic LDS 4 * d * 64 + 2 * PF * 34 floats
 #define BOXF_TS 34                                             // tile row stride (floats): conflict-free column writes and row reads
-template <int KS, bool HASL, int MODE>
-__global__ void __launch_bounds__(64, boxr_waves_f(KS))
+template <int KS, bool HASL, int MODE, int WPS = boxr_waves_f(KS)>   // WPS: waves per SIMD the registers are budgeted for
+__global__ void __launch_bounds__(64, WPS)
 k_boxf(const float* __restrict__ srcW, unsigned img_gap,
        float* __restrict__ dstW, float* __restrict__ dstO, const float* __restrict__ data,
        int n, int C, int ld, int r, BoxDenom denom, size_t sws_img, size_t dws, size_t ws_data,

@@ -810,7 +810,21 @@ int launch_boxf_ks(const Run& r, const float* srcW, const float* srcO, float* ds
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     HIPCHK(attr);
     dim3 grid((unsigned)cdiv(C, 32), (unsigned)W);
-    if (d > 0)
+    // 32 register slots: two waves per SIMD only pay while the LDS part leaves room for them (measured: r = 30,
+    // 28 LDS slots: 10.0 ms per 252 windows at two waves per SIMD, 7.0 ms with the one-wave register budget)
+    bool one_wave = false;
+    if constexpr (KS == 32) {
+        if (d > 14) {
+            static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boxf<KS, true, MODE, 1>),
+                                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            HIPCHK(attr1);
+            hipLaunchKernelGGL((k_boxf<KS, true, MODE, 1>), grid, dim3(64), lds, r.st, srcW, gap, dstW, dstO, data, n, C, ld, rad,
+                               denom, sws_img, dws, ws_data, nanflag);
+            one_wave = true;
+        }
+    }
+    if (one_wave) {
+    } else if (d > 0)
         hipLaunchKernelGGL((k_boxf<KS, true, MODE>), grid, dim3(64), lds, r.st, srcW, gap, dstW, dstO, data, n, C, ld, rad,
                            denom, sws_img, dws, ws_data, nanflag);
     else
