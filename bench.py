@@ -416,6 +416,7 @@ def main():
                     help="rehearsal: map every rank to cuda:0 (with --backend gloo)")
     ap.add_argument("--scatter-bl", type=int, default=8, help="baselines per rank in the N > 1 scatter / gather leg")
     ap.add_argument("--no-scatter", action="store_true")
+    ap.add_argument("--scatter-timeout", type=int, default=240, help="seconds the N > 1 scatter / gather leg may take")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-other-params", action="store_true")
@@ -598,15 +599,6 @@ def main():
     out = None
     flagging.release_workspace()
     torch.cuda.empty_cache()
-    if dist is not None and not args.no_scatter:
-        try:
-            sc = scatter_leg(torch, dist, tricolour_amd, device, rank, world, kw, ncorr, T, F, args.scatter_bl, args.backend)
-        except Exception as e:        # the headline line must survive a failing rehearsal leg
-            sc = dict(error="%s: %s" % (type(e).__name__, e))
-        if rank == 0:
-            res["scatter"] = sc
-        flagging.release_workspace()
-        torch.cuda.empty_cache()
     if rank == 0:
         nwin = min(nbl * ncorr, 1008 if wl != "ska" else 64)
         if not args.no_roofline:
@@ -614,8 +606,35 @@ def main():
                 roofline_boxfilter(torch, device, T, F, kw, nwin)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(kw, T, F, chain=UVCONTSUB_KW if wl == "chain" else None)
+        torch.cuda.empty_cache()
+    leg_failed = False
+    # N > 1: the scatter -> flag -> gather leg comes last, under a watchdog -- a stuck point-to-point transfer
+    # must not take the measured line with it
+    if dist is not None and not args.no_scatter:
+        import threading
+
+        def give_up():
+            if rank == 0:
+                res["scatter"] = dict(error="no completion within %d s" % args.scatter_timeout)
+                print(json.dumps(res))
+                sys.stdout.flush()
+            os._exit(0)
+        timer = threading.Timer(args.scatter_timeout, give_up)
+        timer.daemon = True
+        timer.start()
+        try:
+            sc = scatter_leg(torch, dist, tricolour_amd, device, rank, world, kw, ncorr, T, F, args.scatter_bl, args.backend)
+        except Exception as e:        # the headline line must survive a failing rehearsal leg
+            sc = dict(error="%s: %s" % (type(e).__name__, e))
+            leg_failed = True
+        timer.cancel()
+        if rank == 0:
+            res["scatter"] = sc
+    if rank == 0:
         print(json.dumps(res))
         sys.stdout.flush()
+    if leg_failed:
+        os._exit(0)                   # peers may be stuck in the failed leg's transfers: no further collective
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
