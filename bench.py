@@ -352,6 +352,11 @@ def scatter_leg(torch, dist, tricolour_amd, device, rank, world, kw, ncorr, T, F
         torch.cuda.synchronize()
         dist.barrier()
 
+    # untimed pass over one baseline per rank: the point-to-point connections are set up on first use
+    wshape = (world, ncorr, T, F)
+    wv, wf = D.scatter_windows(vis[:world] if rank == 0 else None, flags[:world] if rank == 0 else None, wshape, src=0, device=comm_dev)
+    D.gather_flags(wf.view(torch.uint8), wshape, dst=0)
+    del wv, wf
     sync()
     t0 = time.perf_counter()
     v, f = D.scatter_windows(vis, flags, shape, src=0, device=comm_dev)
