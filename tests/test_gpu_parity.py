@@ -229,6 +229,8 @@ def _np_median_abs(vals):
     (1, 6000, [0, 1, 2, 3001, 6000], (6, 7)),
     (3, 40000, [0, 3999, 4001, 26214, 40000], (6, 7)),      # two-pass kernel, vector loads, segments that start / end inside a 16-byte group
     (2, 8, [0, 1, 3, 8], (7,)),
+    (2, 1 << 20, [0, 1 << 20], (8, 5)),                     # multi-workgroup select (16 slices per row)
+    (3, 70001, [0, 70001], (8,)),                           # ... scalar loads, ragged last slice
 ])
 def test_median_kernels(gpu, rows, row_len, ends, variants):
     import ctypes as C

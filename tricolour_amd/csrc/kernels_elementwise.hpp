@@ -879,19 +879,35 @@ k_uv_lowpass(const float2* __restrict__ avg, float2* __restrict__ smooth, int F,
 // MAD ignores: prior flags or NaN residual (:1058-1062).  grid (ceil(N/256), n_cp)
 __global__ void k_uv_resid(const float2* __restrict__ vis, const uint8_t* __restrict__ rflags,
                            const float2* __restrict__ smooth, float* __restrict__ absres,
-                           uint8_t* __restrict__ mflags, int T, int F) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t N = (size_t)T * F;
-    if (i >= N) return;
-    size_t cp = blockIdx.y;
-    int f = (int)(i % F);
-    float2 z = vis[cp * N + i], s = smooth[cp * (size_t)F + f];
-    float r = tri_hypotf(z.x - s.x, z.y - s.y);
-    absres[cp * N + i] = r;
-    mflags[cp * N + i] = (rflags[cp * N + i] || isnan(r)) ? 1 : 0;
+                           uint8_t* __restrict__ mflags, unsigned* __restrict__ cnt, int T, int F) {
+    __shared__ unsigned s_cnt;
+    const size_t N = (size_t)T * F;
+    const size_t cp = blockIdx.y;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    unsigned nfl = 0;
+    // 2048 samples per workgroup, 8 per thread
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const size_t i = (size_t)blockIdx.x * 2048 + (size_t)u * 256 + threadIdx.x;
+        if (i < N) {
+            const int f = (int)(i % F);
+            const float2 z = vis[cp * N + i], s = smooth[cp * (size_t)F + f];
+            const float r = tri_hypotf(z.x - s.x, z.y - s.y);
+            const bool fl = rflags[cp * N + i] != 0;
+            absres[cp * N + i] = r;
+            mflags[cp * N + i] = (fl || isnan(r)) ? 1 : 0;
+            nfl += fl ? 1u : 0u;
+        }
+    }
+    // flagged samples of the product (all flagged -> the cycle leaves its flags alone, k_uv_apply): one
+    // global atomic per workgroup
+    for (int o = 32; o > 0; o >>= 1) nfl += __shfl_down(nfl, o, 64);
+    if ((threadIdx.x & 63) == 0 && nfl) atomicAdd(&s_cnt, nfl);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) atomicAdd(&cnt[cp], s_cnt);
 }
-
-// diff = | |absres| - median | in float32 (:1060)
+// (kept for the A/B of the difference image; the flagger forms | |residual| - median | inside the median kernels)
 __global__ void k_uv_diff(const float* __restrict__ absres, const double* __restrict__ med1,
                           float* __restrict__ diff, size_t N) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -505,6 +505,241 @@ k_median2(const float* __restrict__ data, const uint8_t* __restrict__ flags,
 }
 
 // ---------------------------------------------------------------------------
+// K3d  The two-pass select of K3c for a FEW VERY LONG segments (one contiguous segment per window: the
+// whole-window medians of uvcontsub_flagger, flagging.py:1061-1066, 4 M samples each): one workgroup per
+// segment would leave most of the device idle, so each pass is spread over many workgroups per window and
+// the 2048-bin histogram / the candidate list of the selected bin live in global memory:
+//   k_medbig_range    (W)          key range of 2048 evenly spaced samples -> par[w] = {lo, S}
+//   k_medbig_hist     (slices, W)  LDS histogram of a slice, added to ghist[w][2048]
+//   k_medbig_pick     (W)          bin holding rank n/2, keys below it, usability -> par[w]
+//   k_medbig_compact  (slices, W)  keys of that bin appended to gcand[w][], largest key of the lower bins
+//   k_medbig_select   (W)          exact three-digit select on the candidates (or, if the bin was an end bin /
+//                                  overfull, over the whole window by this one workgroup)
+// Keys: |x|, or with a per-window centre m (float32) | |x| - m | -- the second median of the MAD-of-MAD,
+// so the difference image is never written.
+// ---------------------------------------------------------------------------
+#define MEDBIG_SLICE 65536           // samples per workgroup and pass
+#define MEDBIG_CAND 32768            // candidate keys per window (global memory; a 4 M-sample window puts ~10 k keys in a bin)
+struct MedBigPar { unsigned lo, S, bin, exc, total, mode, ncand, below1; };
+
+__device__ __forceinline__ unsigned medbig_key(float x, bool centred, float m) {
+    const float a = centred ? fabsf(fabsf(x) - m) : x;
+    return __float_as_uint(a) & 0x7FFFFFFFu;
+}
+__device__ __forceinline__ unsigned medbig_bin(unsigned k, unsigned lo, unsigned S) {
+    if (k < lo) return 0u;
+    const unsigned b = ((k - lo) >> S) + 1u;
+    return b > 2047u ? 2047u : b;
+}
+// every unflagged key of [i0, i1) of the window, this thread's share (VEC: 16-byte groups, i0 / i1 % 4 == 0)
+template <bool VEC, typename VISIT>
+__device__ __forceinline__ void medbig_enumerate(const float* __restrict__ d, const uint8_t* __restrict__ f, int64_t i0,
+                                                 int64_t i1, bool centred, float m, VISIT&& visit) {
+    const int tid = threadIdx.x;
+    if (VEC) {
+        const float4* d4 = reinterpret_cast<const float4*>(d);
+        const uchar4* f4 = reinterpret_cast<const uchar4*>(f);
+        int64_t i = i0 / 4 + tid;
+        const int64_t e = i1 / 4;
+        for (; i + 768 < e; i += 1024) {
+            float4 dv[4];
+            uchar4 fv[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { dv[q] = d4[i + 256 * q]; fv[q] = f4[i + 256 * q]; }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (!fv[q].x) visit(medbig_key(dv[q].x, centred, m));
+                if (!fv[q].y) visit(medbig_key(dv[q].y, centred, m));
+                if (!fv[q].z) visit(medbig_key(dv[q].z, centred, m));
+                if (!fv[q].w) visit(medbig_key(dv[q].w, centred, m));
+            }
+        }
+        for (; i < e; i += 256) {
+            const float4 dv = d4[i];
+            const uchar4 fv = f4[i];
+            if (!fv.x) visit(medbig_key(dv.x, centred, m));
+            if (!fv.y) visit(medbig_key(dv.y, centred, m));
+            if (!fv.z) visit(medbig_key(dv.z, centred, m));
+            if (!fv.w) visit(medbig_key(dv.w, centred, m));
+        }
+    } else {
+        for (int64_t i = i0 + tid; i < i1; i += 256)
+            if (!f[i]) visit(medbig_key(d[i], centred, m));
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_medbig_range(const float* __restrict__ data, const uint8_t* __restrict__ flags, size_t N,
+               const double* __restrict__ centre, MedBigPar* __restrict__ par, unsigned* __restrict__ ghist) {
+    __shared__ unsigned sh_lo, sh_hi;
+    const size_t w = blockIdx.x;
+    const float* d = data + w * N;
+    const uint8_t* f = flags + w * N;
+    const bool centred = centre != nullptr;
+    const float m = centred ? (float)centre[w] : 0.0f;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) { sh_lo = 0xFFFFFFFFu; sh_hi = 0; }
+    for (int b = tid; b < SEL_BINS; b += 256) ghist[w * SEL_BINS + b] = 0;
+    __syncthreads();
+    unsigned kmin = 0xFFFFFFFFu, kmax = 0;
+    const size_t stride = N / 2048 > 0 ? N / 2048 : 1;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const size_t i = (size_t)(j * 256 + tid) * stride;
+        if (i < N && !f[i]) {
+            const unsigned k = medbig_key(d[i], centred, m);
+            kmin = min(kmin, k);
+            kmax = max(kmax, k);
+        }
+    }
+    kmin = ~wave_max_u32(~kmin);
+    kmax = wave_max_u32(kmax);
+    if (lane == 0) { atomicMin(&sh_lo, kmin); atomicMax(&sh_hi, kmax); }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned lo = sh_lo, hi = sh_hi;
+        unsigned S = 0;
+        if (hi >= lo) while (S < 31 && ((hi - lo) >> S) >= 2046u) S++;
+        MedBigPar p;
+        p.lo = hi >= lo ? lo : 0u;       // nothing sampled: one catch-all range, the pick falls back
+        p.S = hi >= lo ? S : 31u;
+        p.bin = 0; p.exc = 0; p.total = 0; p.mode = 0; p.ncand = 0; p.below1 = 0;
+        par[w] = p;
+    }
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+k_medbig_hist(const float* __restrict__ data, const uint8_t* __restrict__ flags, size_t N,
+              const double* __restrict__ centre, const MedBigPar* __restrict__ par, unsigned* __restrict__ ghist) {
+    __shared__ unsigned hist[SEL_BINS];
+    const size_t w = blockIdx.y;
+    const bool centred = centre != nullptr;
+    const float m = centred ? (float)centre[w] : 0.0f;
+    const unsigned lo = par[w].lo, S = par[w].S;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < SEL_BINS / 256; u++) hist[u * 256 + tid] = 0;
+    __syncthreads();
+    const int64_t i0 = (int64_t)blockIdx.x * MEDBIG_SLICE;
+    const int64_t i1 = i0 + MEDBIG_SLICE < (int64_t)N ? i0 + MEDBIG_SLICE : (int64_t)N;
+    medbig_enumerate<VEC>(data + w * N, flags + w * N, i0, i1, centred, m,
+                          [&](unsigned k) { atomicAdd(&hist[medbig_bin(k, lo, S)], 1u); });
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < SEL_BINS / 256; u++) {
+        const unsigned c = hist[u * 256 + tid];
+        if (c) atomicAdd(&ghist[w * SEL_BINS + u * 256 + tid], c);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_medbig_pick(const unsigned* __restrict__ ghist, MedBigPar* __restrict__ par) {
+    __shared__ unsigned sh[4];
+    const size_t w = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned v[8];
+    {
+        uint4 q0 = reinterpret_cast<const uint4*>(ghist + w * SEL_BINS)[2 * tid];
+        uint4 q1 = reinterpret_cast<const uint4*>(ghist + w * SEL_BINS)[2 * tid + 1];
+        v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w;
+        v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+    }
+    unsigned sacc = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) sacc += v[j];
+    unsigned inc = sacc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        unsigned t2 = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t2;
+    }
+    if (lane == 63) sh[wave] = inc;
+    __syncthreads();
+    unsigned woff = 0, total = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < 4; w2++) {
+        unsigned t2 = sh[w2];
+        if (w2 < wave) woff += t2;
+        total += t2;
+    }
+    const unsigned kk = total >> 1;
+    const unsigned exc = woff + inc - sacc;
+    if (tid == 0) par[w].total = total;
+    if (total > 0 && kk >= exc && kk < exc + sacc) {
+        unsigned c = exc;
+        int j = 0;
+#pragma unroll
+        for (int q = 0; q < 7; q++)
+            if (j == q && kk >= c + v[q]) { c += v[q]; j = q + 1; }
+        const unsigned b = 8u * tid + j;
+        par[w].bin = b;
+        par[w].exc = c;
+        par[w].mode = (b >= 1 && b <= 2046 && v[j] <= MEDBIG_CAND) ? 1u : 0u;
+    }
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+k_medbig_compact(const float* __restrict__ data, const uint8_t* __restrict__ flags, size_t N,
+                 const double* __restrict__ centre, MedBigPar* __restrict__ par, unsigned* __restrict__ gcand) {
+    const size_t w = blockIdx.y;
+    const MedBigPar p = par[w];
+    if (p.mode == 0) return;                                   // the select kernel scans the whole window itself
+    const bool centred = centre != nullptr;
+    const float m = centred ? (float)centre[w] : 0.0f;
+    const int64_t i0 = (int64_t)blockIdx.x * MEDBIG_SLICE;
+    const int64_t i1 = i0 + MEDBIG_SLICE < (int64_t)N ? i0 + MEDBIG_SLICE : (int64_t)N;
+    unsigned mb1 = 0;
+    medbig_enumerate<VEC>(data + w * N, flags + w * N, i0, i1, centred, m, [&](unsigned k) {
+        const unsigned b = medbig_bin(k, p.lo, p.S);
+        if (b == p.bin) gcand[w * MEDBIG_CAND + atomicAdd(&par[w].ncand, 1u)] = k;
+        else if (b < p.bin) mb1 = max(mb1, k + 1);
+    });
+    mb1 = wave_max_u32(mb1);
+    if ((threadIdx.x & 63) == 0 && mb1) atomicMax(&par[w].below1, mb1);
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+k_medbig_select(const float* __restrict__ data, const uint8_t* __restrict__ flags, size_t N,
+                const double* __restrict__ centre, const MedBigPar* __restrict__ par,
+                const unsigned* __restrict__ gcand, double* __restrict__ med) {
+    __shared__ unsigned hist[SEL_BINS];
+    __shared__ unsigned sh[9];
+    const size_t w = blockIdx.x;
+    const MedBigPar p = par[w];
+    const bool centred = centre != nullptr;
+    const float m = centred ? (float)centre[w] : 0.0f;
+    const int tid = threadIdx.x;
+    Sel3State st;
+    unsigned below1 = 1;
+    if (p.mode == 1) {
+        const unsigned ncand = p.ncand;
+        const unsigned* cand = gcand + w * MEDBIG_CAND;          // a few tens of KB: L2-resident for the three passes
+        st = select3(hist, sh, [&](auto&& visit) { for (unsigned i = tid; i < ncand; i += 256) visit(cand[i]); },
+                     (long long)((p.total >> 1) - p.exc));
+        st.n = p.total;
+        below1 = p.below1;
+    } else {
+        st = select3(hist, sh, [&](auto&& visit) {
+            medbig_enumerate<VEC>(data + w * N, flags + w * N, 0, (int64_t)N, centred, m, visit);
+        }, -1);
+    }
+    if (tid == 0) {
+        double r;
+        if (st.n == 0) r = __longlong_as_double(0x7FF8000000000000LL);
+        else if (st.n & 1u) r = (double)__uint_as_float(st.hi);
+        else {
+            const unsigned lo = st.lo_found ? st.lo : below1 - 1;
+            float sm = __uint_as_float(lo) + __uint_as_float(st.hi);
+            r = (double)sm / 2.0;
+        }
+        med[w] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K3b  Wave-per-segment form of k_median for segments of at most 1024 samples
 // (time lines of a window, per-chunk channel runs): the segment's keys stay in
 // registers (16 per lane), each wave owns a 256-bin LDS histogram, and the

@@ -1634,6 +1634,9 @@ extern "C" int tri_test_box_divide(int64_t radius, uint64_t* mismatches, void* s
     return TRI_OK;
 }
 
+static int launch_median_big(hipStream_t st, const float* data, const uint8_t* flags, size_t N, int64_t B, const double* centre,
+                             double* med, MedBigPar* par, unsigned* ghist, unsigned* gcand, bool vec);
+
 // Test hook: exact segmented medians of |x| over unflagged samples of a
 // [n_win][rows][row_len] array; segments [ends[g], ends[g+1]) along each row.
 // variant: 0 = automatic choice, 1 = wave kernel (segments <= 1024),
@@ -1664,6 +1667,22 @@ extern "C" int tri_test_median(const float* data, const uint8_t* flags, double* 
     HIPCHK(hipMemcpy(d_len, len.data(), G * sizeof(int64_t), hipMemcpyHostToDevice));
     size_t WS = (size_t)rows * row_len, RS = (size_t)row_len;
     int R = (int)rows;
+    if (variant == 8) {
+        // multi-workgroup two-pass select (K3d): one segment spanning each whole row
+        if (G != 1 || seg_ends[0] != 0 || seg_ends[1] != row_len) return set_err(TRI_EINVAL, "variant 8 takes one segment covering the row");
+        const int64_t B = n_win * rows;
+        MedBigPar* par = nullptr;
+        unsigned *ghist = nullptr, *gcand = nullptr;
+        HIPCHK(hipMalloc(&par, B * sizeof(MedBigPar)));
+        HIPCHK(hipMalloc(&ghist, B * SEL_BINS * sizeof(unsigned)));
+        HIPCHK(hipMalloc(&gcand, B * (size_t)MEDBIG_CAND * sizeof(unsigned)));
+        int rcb = launch_median_big(st, data, flags, (size_t)row_len, B, nullptr, med, par, ghist, gcand,
+                                    row_len % 4 == 0 && ((uintptr_t)data % 16 == 0) && ((uintptr_t)flags % 4 == 0));
+        HIPCHK(hipStreamSynchronize(st));
+        (void)hipFree(par); (void)hipFree(ghist); (void)hipFree(gcand);
+        (void)hipFree(d_start); (void)hipFree(d_len);
+        return rcb;
+    }
     if (variant == 0) variant = maxlen <= 64 * MW_K ? 1 : (al4 ? 3 : 2);
     if ((variant == 1 || variant == 4) && maxlen > 64 * MW_K) return set_err(TRI_EINVAL, "wave kernel handles segments <= 1024");
     if (variant == 4 && (row_len % 4 != 0 || maxlen + 3 > 64 * MW_K)) return set_err(TRI_EINVAL, "masked vector variant needs row_len % 4 == 0 and segments <= 1021");
@@ -1806,7 +1825,31 @@ extern "C" size_t tri_uvcontsub_workspace_bytes(int64_t batch, int64_t ntime, in
     if (batch <= 0 || ntime <= 0 || nchan <= 0) return 0;
     size_t N = (size_t)ntime * nchan, B = (size_t)batch;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    return al(B * N * 4) * 2 + al(B * N) + al(B * nchan * 8) * 2 + al(B * 8) * 2 + al(B * 4) + 4 * 256;
+    // |residual| image, median flags, mean / smooth spectra, two medians, flag counts, and the global histogram /
+    // candidate list / parameters of the multi-workgroup median (K3d)
+    return al(B * N * 4) + al(B * N) + al(B * nchan * 8) * 2 + al(B * 8) * 2 + al(B * 4) +
+           al(B * SEL_BINS * 4) + al(B * MEDBIG_CAND * 4) + al(B * sizeof(MedBigPar)) + 4 * 256;
+}
+
+// Exact median of | |x| - centre | (centre == nullptr: of |x|) over the unflagged samples of each of B windows of N
+// contiguous samples, many workgroups per window (K3d).
+static int launch_median_big(hipStream_t st, const float* data, const uint8_t* flags, size_t N, int64_t B, const double* centre,
+                             double* med, MedBigPar* par, unsigned* ghist, unsigned* gcand, bool vec) {
+    const unsigned slices = (unsigned)cdiv((int64_t)N, MEDBIG_SLICE);
+    if (B > 65535) return set_err(TRI_EUNSUPPORTED, "too many windows in one median batch");
+    hipLaunchKernelGGL(k_medbig_range, dim3((unsigned)B), dim3(256), 0, st, data, flags, N, centre, par, ghist);
+    if (vec) hipLaunchKernelGGL(k_medbig_hist<true>, dim3(slices, (unsigned)B), dim3(256), 0, st, data, flags, N, centre, par, ghist);
+    else hipLaunchKernelGGL(k_medbig_hist<false>, dim3(slices, (unsigned)B), dim3(256), 0, st, data, flags, N, centre, par, ghist);
+    hipLaunchKernelGGL(k_medbig_pick, dim3((unsigned)B), dim3(256), 0, st, ghist, par);
+    if (vec) {
+        hipLaunchKernelGGL(k_medbig_compact<true>, dim3(slices, (unsigned)B), dim3(256), 0, st, data, flags, N, centre, par, gcand);
+        hipLaunchKernelGGL(k_medbig_select<true>, dim3((unsigned)B), dim3(256), 0, st, data, flags, N, centre, par, gcand, med);
+    } else {
+        hipLaunchKernelGGL(k_medbig_compact<false>, dim3(slices, (unsigned)B), dim3(256), 0, st, data, flags, N, centre, par, gcand);
+        hipLaunchKernelGGL(k_medbig_select<false>, dim3((unsigned)B), dim3(256), 0, st, data, flags, N, centre, par, gcand, med);
+    }
+    LAUNCHCHK();
+    return TRI_OK;
 }
 
 extern "C" int tri_uvcontsub_flagger(const void* vis_c64, const uint8_t* flags, uint8_t* out_flags,
@@ -1829,16 +1872,15 @@ extern "C" int tri_uvcontsub_flagger(const void* vis_c64, const uint8_t* flags, 
     while (tri_uvcontsub_workspace_bytes(Bmax, ntime, nchan) > workspace_bytes) Bmax--;
     Bump b(workspace, workspace_bytes, false);
     float* absres = b.get<float>((size_t)Bmax * N);
-    float* diff = b.get<float>((size_t)Bmax * N);
     uint8_t* mflags = b.get<uint8_t>((size_t)Bmax * N);
     float2* avg = b.get<float2>((size_t)Bmax * F);
     float2* smooth = b.get<float2>((size_t)Bmax * F);
     double* med1 = b.get<double>((size_t)Bmax);
     double* mad = b.get<double>((size_t)Bmax);
     unsigned* cnt = b.get<unsigned>((size_t)Bmax);
-    int64_t* seg = b.get<int64_t>(2);
-    int64_t hseg[2] = {0, (int64_t)N};
-    HIPCHK(hipMemcpyAsync(seg, hseg, sizeof(hseg), hipMemcpyHostToDevice, st));
+    unsigned* ghist = b.get<unsigned>((size_t)Bmax * SEL_BINS);
+    unsigned* gcand = b.get<unsigned>((size_t)Bmax * MEDBIG_CAND);
+    MedBigPar* mpar = b.get<MedBigPar>((size_t)Bmax);
     int K = (int)std::min<int64_t>(taylor_degrees, F);
     bool vec = N % 4 == 0 && (((uintptr_t)workspace) % 16 == 0);
     for (int64_t c0 = 0; c0 < n_cp; c0 += Bmax) {
@@ -1850,21 +1892,17 @@ extern "C" int tri_uvcontsub_flagger(const void* vis_c64, const uint8_t* flags, 
         LAUNCHCHK();
         for (int64_t mi = 0; mi < major_cycles; mi++) {
             HIPCHK(hipMemsetAsync(cnt, 0, (size_t)B * sizeof(unsigned), st));
-            hipLaunchKernelGGL(k_uv_count, dim3((unsigned)cdiv((int64_t)N, 4096), (unsigned)B), dim3(256), 0, st, rf, cnt, N);
             hipLaunchKernelGGL(k_uv_mean, dim3((unsigned)cdiv(F, 256), (unsigned)B), dim3(256), 0, st, v, rf, avg, T, F);
             hipLaunchKernelGGL(k_uv_lowpass, dim3((unsigned)B), dim3(256), 0, st, avg, smooth, F, K);
-            hipLaunchKernelGGL(k_uv_resid, dim3((unsigned)cdiv((int64_t)N, 256), (unsigned)B), dim3(256), 0, st, v, rf, smooth, absres, mflags, T, F);
+            // |vis - smooth|, the median flags and (in the same pass) the number of flagged samples per product
+            hipLaunchKernelGGL(k_uv_resid, dim3((unsigned)cdiv((int64_t)N, 2048), (unsigned)B), dim3(256), 0, st, v, rf, smooth, absres, mflags, cnt, T, F);
             LAUNCHCHK();
-            // nanmedian over the unflagged, non-NaN residuals of each product (:1061)
-            if (vec)
-                hipLaunchKernelGGL(k_median2<true>, dim3(1, (unsigned)B), dim3(256), 0, st, absres, mflags, med1, N, N, (size_t)0, (size_t)1, seg, seg + 1, 1, 1);
-            else
-                hipLaunchKernelGGL(k_median2<false>, dim3(1, (unsigned)B), dim3(256), 0, st, absres, mflags, med1, N, N, (size_t)0, (size_t)1, seg, seg + 1, 1, 1);
-            hipLaunchKernelGGL(k_uv_diff, dim3((unsigned)cdiv((int64_t)N, 256), (unsigned)B), dim3(256), 0, st, absres, med1, diff, N);
-            if (vec)
-                hipLaunchKernelGGL(k_median2<true>, dim3(1, (unsigned)B), dim3(256), 0, st, diff, mflags, mad, N, N, (size_t)0, (size_t)1, seg, seg + 1, 1, 1);
-            else
-                hipLaunchKernelGGL(k_median2<false>, dim3(1, (unsigned)B), dim3(256), 0, st, diff, mflags, mad, N, N, (size_t)0, (size_t)1, seg, seg + 1, 1, 1);
+            // nanmedian over the unflagged, non-NaN residuals of each product (:1061), then the median of
+            // | |residual| - median | (:1064-1066) straight from the residual image
+            int rcm = launch_median_big(st, absres, mflags, N, B, nullptr, med1, mpar, ghist, gcand, vec);
+            if (rcm) return rcm;
+            rcm = launch_median_big(st, absres, mflags, N, B, med1, mad, mpar, ghist, gcand, vec);
+            if (rcm) return rcm;
             hipLaunchKernelGGL(k_uv_apply, dim3((unsigned)cdiv((int64_t)N, 256), (unsigned)B), dim3(256), 0, st, absres, mad, cnt, rf, (float)sigma, mi >= or_original_from_cycle ? 1 : 0, N);
             LAUNCHCHK();
         }
