@@ -463,8 +463,8 @@ def main():
     F = args.chan or (65536 if wl == "ska" else 4096)
     nbl = args.bl or int(os.environ.get("TRI_BENCH_BL", {"slab": "252", "chain": "84", "ska": "32"}[wl]))
     pname = args.params or ("defaults" if wl == "ska" else "stage1")
-    steps = args.steps if args.steps is not None else {"slab": 2, "chain": 1, "ska": 64}[wl]
-    warmup = args.warmup if args.warmup is not None else {"slab": 1, "chain": 1, "ska": 2}[wl]
+    steps = args.steps if args.steps is not None else {"slab": 3, "chain": 1, "ska": 64}[wl]
+    warmup = args.warmup if args.warmup is not None else {"slab": 2, "chain": 1, "ska": 2}[wl]
     kw = PARAM_SETS[pname]
 
     import torch
