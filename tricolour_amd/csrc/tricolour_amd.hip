@@ -1069,6 +1069,14 @@ int background2d(const Run& r) {
             rc = launch_median(r, ws.Bo, ws.bgfFT, ws.med, wsB, N, 0, 1, ws.segB_start, ws.segB_len, 1, G, W, pl.maxchunk * pl.T,
                                T % 4 == 0 && wsB % 4 == 0 && N % 4 == 0);
             if (rc) return rc;
+            static const bool no_fuse = [] { const char* e = getenv("TRI_NO_FUSED_REJECT"); return e && e[0] == '1'; }();
+            if (r.pl.vec && wsB % 4 == 0 && packed && !no_fuse) {
+                // rejection + TF4 re-pack of the flags in one pass
+                hipLaunchKernelGGL(k_reject4_t, dim3((unsigned)cdiv(T / 4, 64), (unsigned)cdiv(Fa, 64), (unsigned)W), dim3(64, 4), 0, r.st,
+                                   ws.Bo, ws.bgfFT, ws.bgfTF, ws.med, ws.d_chunk_of, rej, Fa, T / 4, G, wsB, N);
+                LAUNCHCHK();
+                continue;
+            }
             if (r.pl.vec && wsB % 4 == 0)
                 hipLaunchKernelGGL(k_reject4, grid1(N / 4, W), dim3(256), 0, r.st, ws.Bo, ws.bgfFT, ws.med, ws.d_chunk_of, rej, T / 4, G, N / 4, wsB, N);
             else
