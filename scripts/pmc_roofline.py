@@ -63,4 +63,4 @@ for e in roof:
     elif "frequency-axis" in k:
         rad = int(k.rsplit("r = ", 1)[1])
         ks = 80 if 2 * rad >= 80 else 64 if 2 * rad >= 64 else 32 if 2 * rad >= 32 else 16 if 2 * rad >= 16 else 8
-        emit("boxfilter_s1_r%d" % rad, e, ["k_boxf<%d, %s, 1>" % (ks, "true" if 2 * rad > ks else "false")], "both images + amplitudes in, |data - background| out; 64-byte row segments in, dword-per-lane out")
+        emit("boxfilter_s1_r%d" % rad, e, ["k_boxf<%d, %s, 1," % (ks, "true" if 2 * rad > ks else "false")], "both images + amplitudes in, |data - background| out; 64-byte row segments in, dword-per-lane out")
