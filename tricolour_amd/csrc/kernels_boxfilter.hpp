@@ -20,7 +20,9 @@
 // numba does) and writes rows [0,n) of dstW / dstO.
 // grid (ceil(C/BLK), W, 2 images), block BLK
 // ---------------------------------------------------------------------------
+#ifndef CF_U
 #define CF_U 8
+#endif
 template <int SRCMODE>
 __global__ void __launch_bounds__(256)
 k_colfilter(float* __restrict__ bufW, float* __restrict__ bufO,
