@@ -452,6 +452,19 @@ __global__ void k_or_spec16(uint8_t* __restrict__ flags, const uint8_t* __restri
     *pf = or4(*pf, sp);
 }
 
+// The same update on the FT image: flagsFT[w][f][t..t+15] |= spec_rows[w][f].
+// A spectral flag covers its channel's whole row, so only the rows of flagged
+// channels are written -- the FT image stays current without transposing the
+// TF one again.
+__global__ void k_or_spec_ft16(uint8_t* __restrict__ flagsFT, const uint8_t* __restrict__ spec_rows, int T16, int Fa) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)T16 * Fa) return;
+    size_t win = blockIdx.y;
+    int f = (int)(i / T16);
+    if (!spec_rows[win * (size_t)Fa + f]) return;
+    reinterpret_cast<uint4*>(flagsFT + win * (size_t)T16 * 16 * Fa)[i] = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
+}
+
 // _combine_flags (flagging.py:784-816), 16 channels per thread
 __global__ void k_combine16(const uint8_t* __restrict__ spec_rows, const uint8_t* __restrict__ tflags,
                             const uint8_t* __restrict__ fflags, uint8_t* __restrict__ comb, int T,

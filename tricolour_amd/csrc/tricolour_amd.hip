@@ -936,7 +936,7 @@ int spectrum_background(const Run& r) {
 // In: dataTF / dataFT, flagsTF (spectral flags already OR-ed in).  Out: the
 // background in FT layout in rows [0,Fa) of ws.Bo and the residual
 // data - background in rows [0,Fa) of ws.Bw (window stride PF*T).
-int background2d(const Run& r) {
+int background2d(const Run& r, bool flagsFT_current) {
     const Plan& pl = r.pl;
     const Ws& ws = r.ws;
     int T = (int)pl.T, Fa = (int)pl.Fa, G = (int)pl.G;
@@ -950,7 +950,8 @@ int background2d(const Run& r) {
     // FT byte image viewed as [Fa][T/4] words.
     static const bool no_pack = [] { const char* e = getenv("TRI_NO_PACKED_FLAGS"); return e && e[0] == '1'; }();
     const bool packed = !no_pack && (T % 4 == 0) && (N % 4 == 0);
-    int rc = launch_transpose<uint8_t>(r, ws.flagsTF, ws.bgfFT, T, Fa, N, N, W);
+    int rc = flagsFT_current ? launch_u8<0>(r, ws.flagsFT, ws.bgfFT, N, N, N, W)
+                             : launch_transpose<uint8_t>(r, ws.flagsTF, ws.bgfFT, T, Fa, N, N, W);
     if (rc) return rc;
     if (packed) {
         rc = launch_transpose<float>(r, reinterpret_cast<const float*>(ws.bgfFT), reinterpret_cast<float*>(ws.bgfTF), Fa, T / 4, N / 4, N / 4, W);
@@ -1147,16 +1148,22 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
     if (rc) return rc;
 
     // flagging.py:954  flags |= spec_flags
+    // With whole 16-byte groups along time the FT copy of the flags is updated
+    // in place (rows of flagged channels only) instead of being transposed again.
+    static const bool no_ft_or = [] { const char* e = getenv("TRI_NO_FT_SPEC_OR"); return e && e[0] == '1'; }();
+    const bool ft_current = pl.vec && !no_ft_or && T % 16 == 0;
     if (pl.vec) {
         hipLaunchKernelGGL(k_spec_rows, dim3((unsigned)cdiv(nS, 256)), dim3(256), 0, r.st, ws.sout, ws.srows, Fa, Wn);
         hipLaunchKernelGGL(k_or_spec16, grid1(N / 16, W), dim3(256), 0, r.st, ws.flagsTF, ws.srows, T, Fa / 16);
+        if (ft_current)
+            hipLaunchKernelGGL(k_or_spec_ft16, grid1(N / 16, W), dim3(256), 0, r.st, ws.flagsFT, ws.srows, T / 16, Fa);
     } else {
         hipLaunchKernelGGL(k_or_spec, grid1(N, W), dim3(256), 0, r.st, ws.flagsTF, ws.sout, T, Fa, Wn);
     }
     LAUNCHCHK();
 
     // flagging.py:957-962  2-D background (FT layout, ws.Bo), then the residual
-    rc = background2d(r);
+    rc = background2d(r, ft_current);
     if (rc) return rc;
     if (tap && r.dbg) {
         HIPCHK(hipMemcpyAsync(r.dbg->f32 + Fa, ws.Bo, N * sizeof(float), hipMemcpyDeviceToDevice, r.st));
@@ -1170,8 +1177,10 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
 
     // flagging.py:964  SumThreshold along time.  MAD per channel over time =
     // contiguous rows of the FT layout; flags = input | spectral flags.
-    rc = launch_transpose<uint8_t>(r, ws.flagsTF, ws.flagsFT, T, Fa, N, N, W);
-    if (rc) return rc;
+    if (!ft_current) {
+        rc = launch_transpose<uint8_t>(r, ws.flagsTF, ws.flagsFT, T, Fa, N, N, W);
+        if (rc) return rc;
+    }
     rc = launch_median(r, residFT, ws.flagsFT, ws.med, wsB, N, (size_t)T, 1, ws.segT_start, ws.segT_len, Fa, 1, W, pl.T, false, T % 4 == 0, true);
     if (rc) return rc;
     rc = launch_colst(r, pl.swT, residTF, ws.med, ws.tflTF, ws.d_tends, T, Fa, 1, N, N, W);
