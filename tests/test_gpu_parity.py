@@ -113,6 +113,38 @@ def test_random_windows_multi_batch(gpu, oracle):
     assert np.array_equal(out_all, exp)
 
 
+def test_nan_bitmap_is_per_batch(gpu, oracle):
+    """Cached-amplitude path: the NaN bitmap the final pass reads instead of the amplitudes is rebuilt
+    for every internal batch (NaNs in the first and the last window only, one window per batch)."""
+    import ctypes
+    from tricolour_amd import _lib, flagging
+    rs = np.random.RandomState(23)
+    shape = (4, 1, 32, 64)
+    vis = (rs.standard_normal(shape) + 1j * rs.standard_normal(shape)).astype(np.complex64)
+    vis[0, 0, 3, 5] = np.nan
+    vis[3, 0, 30, 63] = complex(1.0, np.nan)
+    vis[1, 0, 9] *= 7
+    flags = rs.uniform(size=shape) < 0.03
+    kw = dict(num_major_iterations=2)
+    exp = oracle.sum_threshold_flagger(vis, flags, **kw)
+    assert exp[0, 0, 3, 5] and exp[3, 0, 30, 63]
+    old = os.environ.get("TRICOLOUR_AMD_WORKSPACE_GB")
+    try:
+        p = flagging.prepare_params(32, 64, **kw)
+        one = _lib.lib().tri_workspace_bytes(1, 32, 64, ctypes.byref(p))
+        os.environ["TRICOLOUR_AMD_WORKSPACE_GB"] = repr((one + 4096) / 2**30)
+        flagging.release_workspace()
+        out = gpu.sum_threshold_flagger(vis, flags, **kw)
+    finally:
+        if old is None:
+            os.environ.pop("TRICOLOUR_AMD_WORKSPACE_GB", None)
+        else:
+            os.environ["TRICOLOUR_AMD_WORKSPACE_GB"] = old
+        flagging.release_workspace()
+    assert np.array_equal(out, exp)
+    assert np.array_equal(gpu.sum_threshold_flagger(vis, flags, **kw), exp)
+
+
 def test_inputs_not_modified_and_torch_roundtrip(gpu, oracle):
     """tests/test_flagging.py:562-567 of the reference: inputs untouched."""
     import torch
@@ -648,7 +680,7 @@ print("DIFF", bad)
 @pytest.mark.parametrize("knob", ["TRI_NO_AMPL_CACHE", "TRI_FILTER_NO_FUSED_DIV", "TRI_FILTER_NO_TIN", "TRI_FILTER_NO_LANE4",
                                   "TRI_NO_PACKED_FLAGS", "TRI_FILTER_MULTIPASS", "TRI_ST_GENERIC", "TRI_ST_REGISTER",
                                   "TRI_FILTER_DIRECT_FT", "TRI_FILTER_NO_REGRING", "TRI_FILTER_NO_REGRING_F", "TRI_MEDIAN_3PASS",
-                                  "TRI_NO_FUSED_REJECT", "TRI_NO_FT_SPEC_OR"])
+                                  "TRI_NO_FUSED_REJECT", "TRI_NO_FT_SPEC_OR", "TRI_NO_FUSED_BEGIN"])
 def test_alternate_kernel_paths(gpu, knob):
     """Every fallback / A-B path selectable through an environment knob (read once
     per process, hence the subprocess) stays bit-exact against the oracle."""

@@ -67,29 +67,67 @@ __global__ void k_transpose(const T* __restrict__ src, T* __restrict__ dst, int 
 }
 
 // uint8 transpose with 4-byte accesses on both sides (R % 4 == 0, C % 4 == 0):
-// 64x64 byte tile; thread (tx, ty) of a (16,16) block moves uchar4 groups.
-__global__ void k_transpose_u8x4(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int R,
-                                 int C, size_t src_ws, size_t dst_ws) {
-    __shared__ uint8_t tile[64][68];
+// a 128 x 64 byte tile goes through LDS as words; each thread then takes 4x4
+// byte blocks (four words of four consecutive source rows), transposes them in
+// registers with byte permutes and writes four words -- 128-byte runs along
+// every output row.
+//   COPY: the source words are also written, untransposed, to `copy`
+//   ZERO: data[c][r] (float, the output's layout) is zeroed wherever the
+//         transposed byte is non-zero (k_zero_flagged4's job, flags in hand)
+// Together: the start of a major iteration (flagsTF = running flags, flagsFT
+// = their transpose, dataFT masked) in one pass over the flags.
+template <bool COPY, bool ZERO>
+__global__ __launch_bounds__(256) void k_transpose_u8w(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                       uint8_t* __restrict__ copy, float* __restrict__ data, int R, int C,
+                                                       size_t src_ws, size_t dst_ws, size_t copy_ws, size_t data_ws) {
+    __shared__ unsigned tile[128][17];
     const uint8_t* s = src + (size_t)blockIdx.z * src_ws;
     uint8_t* d = dst + (size_t)blockIdx.z * dst_ws;
-    int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
-    int tx = threadIdx.x, ty = threadIdx.y;   // 16 x 16
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 128;
+    const int tid = threadIdx.x;
+    {
+        const int tx = tid & 15, ty = tid >> 4;
+        const int c = c0 + 4 * tx;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        int r = r0 + ty + 16 * j, c = c0 + 4 * tx;
-        uchar4 v = make_uchar4(0, 0, 0, 0);
-        if (r < R && c < C) v = *reinterpret_cast<const uchar4*>(s + (size_t)r * C + c);
-        *reinterpret_cast<uchar4*>(&tile[ty + 16 * j][4 * tx]) = v;
+        for (int j = 0; j < 8; j++) {
+            const int rr = ty + 16 * j, r = r0 + rr;
+            unsigned v = 0;
+            if (r < R && c < C) {
+                v = *reinterpret_cast<const unsigned*>(s + (size_t)r * C + c);
+                if (COPY) *reinterpret_cast<unsigned*>(copy + (size_t)blockIdx.z * copy_ws + (size_t)r * C + c) = v;
+            }
+            tile[rr][tx] = v;
+        }
     }
     __syncthreads();
+    const int bx = tid & 31, q0 = tid >> 5;
+    const int r = r0 + 4 * bx;   // four source rows = one output word
+    if (r >= R) return;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        int c = c0 + ty + 16 * j, r = r0 + 4 * tx;   // output row = source column
-        if (c < C && r < R) {
-            int cc = ty + 16 * j;
-            uchar4 v = make_uchar4(tile[4 * tx][cc], tile[4 * tx + 1][cc], tile[4 * tx + 2][cc], tile[4 * tx + 3][cc]);
-            *reinterpret_cast<uchar4*>(d + (size_t)c * R + r) = v;
+    for (int h = 0; h < 2; h++) {
+        const int q = q0 + 8 * h;
+        const unsigned a0 = tile[4 * bx][q], a1 = tile[4 * bx + 1][q], a2 = tile[4 * bx + 2][q], a3 = tile[4 * bx + 3][q];
+        // byte b of a_k = src[r + k][c0 + 4q + b]; output word b = bytes b of a0..a3
+        const unsigned t0 = __builtin_amdgcn_perm(a1, a0, 0x05010400u), t1 = __builtin_amdgcn_perm(a1, a0, 0x07030602u);
+        const unsigned u0 = __builtin_amdgcn_perm(a3, a2, 0x05010400u), u1 = __builtin_amdgcn_perm(a3, a2, 0x07030602u);
+        const unsigned o[4] = {__builtin_amdgcn_perm(u0, t0, 0x05040100u), __builtin_amdgcn_perm(u0, t0, 0x07060302u),
+                               __builtin_amdgcn_perm(u1, t1, 0x05040100u), __builtin_amdgcn_perm(u1, t1, 0x07060302u)};
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int c = c0 + 4 * q + b;
+            if (c >= C) break;
+            *reinterpret_cast<unsigned*>(d + (size_t)c * R + r) = o[b];
+            if (ZERO && o[b]) {
+                const unsigned f = o[b];
+                float4* pd = reinterpret_cast<float4*>(data + (size_t)blockIdx.z * data_ws + (size_t)c * R + r);
+                float4 x = *pd;
+                // the running flags only grow: from the second iteration on most of these are zero already
+                const bool dirty = ((f & 0xFFu) && __float_as_uint(x.x)) || ((f & 0xFF00u) && __float_as_uint(x.y)) ||
+                                   ((f & 0xFF0000u) && __float_as_uint(x.z)) || ((f & 0xFF000000u) && __float_as_uint(x.w));
+                if (dirty)
+                    *pd = make_float4((f & 0xFFu) ? 0.0f : x.x, (f & 0xFF00u) ? 0.0f : x.y, (f & 0xFF0000u) ? 0.0f : x.z,
+                                      (f & 0xFF000000u) ? 0.0f : x.w);
+            }
         }
     }
 }
@@ -382,7 +420,7 @@ __global__ void k_prepare4(const void* __restrict__ vis, const uint8_t* __restri
 // (flagged -> sum 0, count 0 -> value 0, flagging.py:858-870).
 template <int VD>
 __global__ void k_amplitude4(const void* __restrict__ vis, float* __restrict__ ampl,
-                             uint8_t* __restrict__ iter, size_t n4) {
+                             uint8_t* __restrict__ iter, uint16_t* __restrict__ nanmask, size_t n4) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // group of 4 samples, flat over the batch
     if (i >= n4) return;
     float a[4];
@@ -401,6 +439,12 @@ __global__ void k_amplitude4(const void* __restrict__ vis, float* __restrict__ a
     const unsigned nanb = (isnan(a[0]) ? 1u : 0u) | (isnan(a[1]) ? 0x100u : 0u) | (isnan(a[2]) ? 0x10000u : 0u) |
                           (isnan(a[3]) ? 0x1000000u : 0u);
     if (nanb) reinterpret_cast<unsigned*>(iter)[i] |= nanb;
+    // NaN bitmap, 16 samples (4 neighbouring threads; n4 % 4 == 0) per word: k_final16's NaN test
+    // then costs 1/8 B per sample instead of re-reading the amplitudes
+    unsigned m = ((isnan(a[0]) ? 1u : 0u) | (isnan(a[1]) ? 2u : 0u) | (isnan(a[2]) ? 4u : 0u) | (isnan(a[3]) ? 8u : 0u)) << (4 * (threadIdx.x & 3));
+    m |= __shfl_xor(m, 1, 64);
+    m |= __shfl_xor(m, 2, 64);
+    if ((threadIdx.x & 3) == 0) nanmask[i >> 2] = (uint16_t)m;
 }
 
 // data[i] = 0 where flags[i] != 0, four samples per thread; groups without a flag
@@ -549,7 +593,9 @@ __global__ void k_colcount(const uint8_t* __restrict__ dil, int* __restrict__ co
     reinterpret_cast<int4*>(colcnt)[win * (size_t)F4 + f4] = make_int4((int)c0, (int)c1, (int)c2, (int)c3);
 }
 
-// k_final, 16 samples per thread
+// k_final, 16 samples per thread.  VD == TRI_VIS_NANMASK: `vis` is k_amplitude4's
+// NaN bitmap of the batch (one uint16 per thread here).
+#define TRI_VIS_NANMASK (-1000)
 template <int VD>
 __global__ void k_final16(const uint8_t* __restrict__ dil, const int* __restrict__ rowcnt,
                           const int* __restrict__ colcnt, const void* __restrict__ vis,
@@ -565,12 +611,17 @@ __global__ void k_final16(const uint8_t* __restrict__ dil, const int* __restrict
     bool rowall = (double)rowcnt[win * (size_t)T + t] > row_limit;
     const int4* cc = reinterpret_cast<const int4*>(colcnt + win * (size_t)F16 * 16) + (size_t)f16 * 4;
     unsigned o[4];
+    unsigned nm = 0;
+    if (VD == TRI_VIS_NANMASK) nm = reinterpret_cast<const uint16_t*>(vis)[a16];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         int4 c4 = cc[q];
         int cv[4] = {c4.x, c4.y, c4.z, c4.w};
         unsigned nanb = 0;
-        if (VD == TRI_VIS_C64) {
+        if (VD == TRI_VIS_NANMASK) {
+            const unsigned b = nm >> (4 * q);
+            nanb = (b & 1u) | ((b & 2u) << 7) | ((b & 4u) << 14) | ((b & 8u) << 21);
+        } else if (VD == TRI_VIS_C64) {
             const float4* vp = reinterpret_cast<const float4*>(vis) + (a16 * 16 + q * 4) / 2;
             float4 z0 = vp[0], z1 = vp[1];
             nanb = ((isnan(z0.x) || isnan(z0.y)) ? 1u : 0u) | ((isnan(z0.z) || isnan(z0.w)) ? 0x100u : 0u) |

@@ -149,6 +149,7 @@ struct Ws {
     // spectrum layout [Fa][Wb]
     float *sdata, *sw, *so, *sres;
     uint8_t *sflags, *sbgf, *sout, *srows;   // srows: sout as rows [Wb][Fa]
+    uint16_t* nanmask;                       // cached-amplitude path: one NaN bit per sample, 16 samples per word
     float* srowsf;                           // spectrum residuals as rows [Wb][Fa] (median input)
     uint8_t* srowsu;                         // their flags as rows
     double* smed;     // [Wb][G]
@@ -199,6 +200,7 @@ static void carve(const Plan& pl, int64_t Wb, void* base, size_t cap, bool dry, 
     ws->dil = b.get<uint8_t>(W * T * F);
     ws->rowcnt = b.get<int>(W * T);
     ws->colcnt = b.get<int>(W * F);
+    ws->nanmask = b.get<uint16_t>(W * N / 16 + 8);
     ws->med = b.get<double>(W * std::max(Fa, T * G));
     size_t PS = (size_t)pl.PF;  // spectrum padded length
     ws->sdata = b.get<float>(Fa * W);
@@ -695,7 +697,9 @@ int launch_transpose(const Run& r, const T* src, T* dst, int R, int C, size_t sw
     dim3 grid((unsigned)cdiv(C, 64), (unsigned)cdiv(R, 64), (unsigned)W);
     if (sizeof(T) == 1 && R % 4 == 0 && C % 4 == 0 && sws % 4 == 0 && dws % 4 == 0 &&
         ((uintptr_t)src % 4 == 0) && ((uintptr_t)dst % 4 == 0)) {
-        hipLaunchKernelGGL(k_transpose_u8x4, grid, dim3(16, 16), 0, r.st, (const uint8_t*)src, (uint8_t*)dst, R, C, sws, dws);
+        dim3 gridw((unsigned)cdiv(C, 64), (unsigned)cdiv(R, 128), (unsigned)W);
+        hipLaunchKernelGGL((k_transpose_u8w<false, false>), gridw, dim3(256), 0, r.st, (const uint8_t*)src, (uint8_t*)dst,
+                           (uint8_t*)nullptr, (float*)nullptr, R, C, sws, dws, (size_t)0, (size_t)0);
         LAUNCHCHK();
         return TRI_OK;
     }
@@ -1109,7 +1113,17 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
     int rc;
 
     // flagging.py:756  _average_freq
-    if (r.ampl_cached) {
+    static const bool no_fused_begin = [] { const char* e = getenv("TRI_NO_FUSED_BEGIN"); return e && e[0] == '1'; }();
+    const bool fused_begin = r.ampl_cached && !no_fused_begin && T % 4 == 0 && Fa % 4 == 0 && N % 4 == 0 &&
+                             ((uintptr_t)iter_flags % 4 == 0);
+    if (fused_begin) {
+        // flagsTF = running flags (NaNs already folded in), flagsFT = their transpose,
+        // cached FT amplitudes masked -- one pass over the flags
+        dim3 gridw((unsigned)cdiv(Fa, 64), (unsigned)cdiv(T, 128), (unsigned)W);
+        hipLaunchKernelGGL((k_transpose_u8w<true, true>), gridw, dim3(256), 0, r.st, iter_flags, ws.flagsFT, ws.flagsTF, ws.dataFT,
+                           T, Fa, N, N, N, N);
+        LAUNCHCHK();
+    } else if (r.ampl_cached) {
         // amplitudes (both layouts) were made once for the batch; this iteration's
         // flags = running flags (NaNs already folded in)
         rc = launch_u8<0>(r, iter_flags, ws.flagsTF, N, N, N, W);
@@ -1123,9 +1137,11 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
         rc = launch_transpose<float>(r, ws.dataTF, ws.dataFT, T, Fa, N, N, W);
         if (rc) return rc;
     }
-    rc = launch_transpose<uint8_t>(r, ws.flagsTF, ws.flagsFT, T, Fa, N, N, W);
-    if (rc) return rc;
-    if (r.ampl_cached) {
+    if (!fused_begin) {
+        rc = launch_transpose<uint8_t>(r, ws.flagsTF, ws.flagsFT, T, Fa, N, N, W);
+        if (rc) return rc;
+    }
+    if (r.ampl_cached && !fused_begin) {
         hipLaunchKernelGGL(k_zero_flagged4, grid1(N / 4, W), dim3(256), 0, r.st, ws.flagsFT, ws.dataFT, N / 4, N, N);
         LAUNCHCHK();
     }
@@ -1239,7 +1255,7 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
     double col_limit = (double)T * p->flag_all_time_frac;
     if (pl.vec)
         if (r.ampl_cached)   // isnan(|vis|) from the cached amplitudes: half the bytes of the complex visibilities
-            hipLaunchKernelGGL(k_final16<TRI_VIS_F32>, grid1(NF / 16, W), dim3(256), 0, r.st, ws.dil, ws.rowcnt, ws.colcnt, (const void*)ws.dataTF, out_flags, iter_flags, T, F / 16, row_limit, col_limit, update_iter ? 1 : 0);
+            hipLaunchKernelGGL(k_final16<TRI_VIS_NANMASK>, grid1(NF / 16, W), dim3(256), 0, r.st, ws.dil, ws.rowcnt, ws.colcnt, (const void*)ws.nanmask, out_flags, iter_flags, T, F / 16, row_limit, col_limit, update_iter ? 1 : 0);
         else
             hipLaunchKernelGGL(k_final16<VD>, grid1(NF / 16, W), dim3(256), 0, r.st, ws.dil, ws.rowcnt, ws.colcnt, vis, out_flags, iter_flags, T, F / 16, row_limit, col_limit, update_iter ? 1 : 0);
     else
@@ -1294,9 +1310,9 @@ int process_windows(Run& r, const void* vis, int vis_dtype, const uint8_t* flags
         if (r.ampl_cached) {
             const size_t n4 = (size_t)r.Wb * NF / 4;
             if (vis_dtype == TRI_VIS_C64)
-                hipLaunchKernelGGL(k_amplitude4<TRI_VIS_C64>, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, r.st, (const void*)vis_b, r.ws.dataTF, r.ws.iter, n4);
+                hipLaunchKernelGGL(k_amplitude4<TRI_VIS_C64>, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, r.st, (const void*)vis_b, r.ws.dataTF, r.ws.iter, r.ws.nanmask, n4);
             else
-                hipLaunchKernelGGL(k_amplitude4<TRI_VIS_F32>, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, r.st, (const void*)vis_b, r.ws.dataTF, r.ws.iter, n4);
+                hipLaunchKernelGGL(k_amplitude4<TRI_VIS_F32>, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, r.st, (const void*)vis_b, r.ws.dataTF, r.ws.iter, r.ws.nanmask, n4);
             LAUNCHCHK();
             rc = launch_transpose<float>(r, r.ws.dataTF, r.ws.dataFT, (int)T, (int)r.pl.Fa, NF, NF, r.Wb);
             if (rc) return rc;
