@@ -680,7 +680,7 @@ print("DIFF", bad)
 @pytest.mark.parametrize("knob", ["TRI_NO_AMPL_CACHE", "TRI_FILTER_NO_FUSED_DIV", "TRI_FILTER_NO_TIN", "TRI_FILTER_NO_LANE4",
                                   "TRI_NO_PACKED_FLAGS", "TRI_FILTER_MULTIPASS", "TRI_ST_GENERIC", "TRI_ST_REGISTER",
                                   "TRI_FILTER_DIRECT_FT", "TRI_FILTER_NO_REGRING", "TRI_FILTER_NO_REGRING_F", "TRI_MEDIAN_3PASS",
-                                  "TRI_NO_FUSED_REJECT", "TRI_NO_FT_SPEC_OR", "TRI_NO_FUSED_BEGIN"])
+                                  "TRI_NO_FUSED_REJECT", "TRI_NO_FT_SPEC_OR", "TRI_NO_FUSED_BEGIN", "TRI_NO_FUSED_DILATE"])
 def test_alternate_kernel_paths(gpu, knob):
     """Every fallback / A-B path selectable through an environment knob (read once
     per process, hence the subprocess) stays bit-exact against the oracle."""

@@ -496,6 +496,19 @@ __global__ void k_or_spec16(uint8_t* __restrict__ flags, const uint8_t* __restri
     *pf = or4(*pf, sp);
 }
 
+// flags[w][t][f..f+15] |= spec_rows[w][f..f+15] | more[w][t][f..f+15]
+__global__ void k_or_spec_more16(uint8_t* __restrict__ flags, const uint8_t* __restrict__ spec_rows,
+                                 const uint8_t* __restrict__ more, int T, int Fa16) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)T * Fa16) return;
+    size_t win = blockIdx.y;
+    int f16 = (int)(i % Fa16);
+    uint4 sp = reinterpret_cast<const uint4*>(spec_rows + win * (size_t)Fa16 * 16)[f16];
+    size_t a = win * (size_t)T * Fa16 + i;
+    uint4* pf = reinterpret_cast<uint4*>(flags) + a;
+    *pf = or4(or4(*pf, sp), reinterpret_cast<const uint4*>(more)[a]);
+}
+
 // The same update on the FT image: flagsFT[w][f][t..t+15] |= spec_rows[w][f].
 // A spectral flag covers its channel's whole row, so only the rows of flagged
 // channels are written -- the FT image stays current without transposing the
@@ -530,6 +543,60 @@ __global__ void k_combine16(const uint8_t* __restrict__ spec_rows, const uint8_t
         }
     }
     reinterpret_cast<uint4*>(comb)[base + i] = v;
+}
+
+// k_combine16 followed by k_unaverage16<-1, 3> in one pass (time smearing over
+// [t + lo, t + hi), then frequency smearing over [f - 1, f + 1]) without the
+// intermediate image: the two bytes a 16-channel group needs from its
+// neighbours come from the adjacent lanes (or, at wave edges, from memory).
+// grid (ceil(F16/64), T, W), block 64
+__global__ __launch_bounds__(64) void k_combine_dilate16(const uint8_t* __restrict__ spec_rows, const uint8_t* __restrict__ tflags,
+                                                        const uint8_t* __restrict__ fflags, uint8_t* __restrict__ dil,
+                                                        int* __restrict__ rowcnt, int T, int F16, int lo, int hi) {
+    const int lane = threadIdx.x;
+    const int f16 = blockIdx.x * 64 + lane;
+    const int t = blockIdx.y;
+    const size_t win = blockIdx.z;
+    const size_t base = win * (size_t)T * F16;
+    const int t0 = max(t + lo, 0), t1 = min(t + hi, T);
+    const bool in = f16 < F16;
+    uint4 c = make_uint4(0, 0, 0, 0);
+    if (in && t1 > t0) {
+        c = reinterpret_cast<const uint4*>(spec_rows + win * (size_t)F16 * 16)[f16];
+        const uint4* tp = reinterpret_cast<const uint4*>(tflags) + base;
+        const uint4* fp = reinterpret_cast<const uint4*>(fflags) + base;
+        for (int tt = t0; tt < t1; tt++) {
+            size_t a = (size_t)tt * F16 + f16;
+            c = or4(c, or4(tp[a], fp[a]));
+        }
+    }
+    auto edge = [&](int g, int b) -> unsigned {   // combined byte b of group g
+        if (g < 0 || g >= F16 || t1 <= t0) return 0u;
+        unsigned v = spec_rows[(win * (size_t)F16 + g) * 16 + b];
+        for (int tt = t0; tt < t1; tt++) {
+            size_t a = (base + (size_t)tt * F16 + g) * 16 + b;
+            v |= (unsigned)tflags[a] | (unsigned)fflags[a];
+        }
+        return v;
+    };
+    unsigned prev = __shfl_up(c.w >> 24, 1, 64), next = __shfl_down(c.x & 0xFFu, 1, 64);
+    if (lane == 0) prev = edge(f16 - 1, 15);
+    if (lane == 63) next = edge(f16 + 1, 0);
+    int cnt = 0;
+    if (in) {
+        const unsigned w[4] = {c.x, c.y, c.z, c.w};
+        unsigned o[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned left = (w[j] << 8) | (j > 0 ? w[j - 1] >> 24 : prev & 0xFFu);
+            const unsigned right = (w[j] >> 8) | ((j < 3 ? w[j + 1] & 0xFFu : next & 0xFFu) << 24);
+            o[j] = (w[j] | left | right) & 0x01010101u;
+            cnt += __popc(o[j]);
+        }
+        reinterpret_cast<uint4*>(dil)[base + (size_t)t * F16 + f16] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    if (lane == 0 && cnt) atomicAdd(&rowcnt[win * (size_t)T + t], cnt);
 }
 
 // _unaverage_freq (flagging.py:896-908) for average_freq == 1, frequency

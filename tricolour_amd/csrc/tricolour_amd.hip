@@ -940,6 +940,11 @@ int spectrum_background(const Run& r) {
 // In: dataTF / dataFT, flagsTF (spectral flags already OR-ed in).  Out: the
 // background in FT layout in rows [0,Fa) of ws.Bo and the residual
 // data - background in rows [0,Fa) of ws.Bw (window stride PF*T).
+static bool bg_flags_packed(int T, size_t N) {
+    static const bool no_pack = [] { const char* e = getenv("TRI_NO_PACKED_FLAGS"); return e && e[0] == '1'; }();
+    return !no_pack && (T % 4 == 0) && (N % 4 == 0);
+}
+
 int background2d(const Run& r, bool flagsFT_current) {
     const Plan& pl = r.pl;
     const Ws& ws = r.ws;
@@ -952,8 +957,7 @@ int background2d(const Run& r, bool flagsFT_current) {
     // image (general case) or, when T % 4 == 0, packed four times per word
     // ("TF4": [T/4][Fa] uint32) -- which is exactly the 32-bit transpose of the
     // FT byte image viewed as [Fa][T/4] words.
-    static const bool no_pack = [] { const char* e = getenv("TRI_NO_PACKED_FLAGS"); return e && e[0] == '1'; }();
-    const bool packed = !no_pack && (T % 4 == 0) && (N % 4 == 0);
+    const bool packed = bg_flags_packed(T, N);
     int rc = flagsFT_current ? launch_u8<0>(r, ws.flagsFT, ws.bgfFT, N, N, N, W)
                              : launch_transpose<uint8_t>(r, ws.flagsTF, ws.bgfFT, T, Fa, N, N, W);
     if (rc) return rc;
@@ -1168,9 +1172,13 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
     // in place (rows of flagged channels only) instead of being transposed again.
     static const bool no_ft_or = [] { const char* e = getenv("TRI_NO_FT_SPEC_OR"); return e && e[0] == '1'; }();
     const bool ft_current = pl.vec && !no_ft_or && T % 16 == 0;
+    // ... and when the background works from the FT image alone (packed flags), the TF image is
+    // not read before the time flags are OR-ed in: both updates then share one pass.
+    const bool defer_tf = ft_current && bg_flags_packed(T, N);
     if (pl.vec) {
         hipLaunchKernelGGL(k_spec_rows, dim3((unsigned)cdiv(nS, 256)), dim3(256), 0, r.st, ws.sout, ws.srows, Fa, Wn);
-        hipLaunchKernelGGL(k_or_spec16, grid1(N / 16, W), dim3(256), 0, r.st, ws.flagsTF, ws.srows, T, Fa / 16);
+        if (!defer_tf)
+            hipLaunchKernelGGL(k_or_spec16, grid1(N / 16, W), dim3(256), 0, r.st, ws.flagsTF, ws.srows, T, Fa / 16);
         if (ft_current)
             hipLaunchKernelGGL(k_or_spec_ft16, grid1(N / 16, W), dim3(256), 0, r.st, ws.flagsFT, ws.srows, T / 16, Fa);
     } else {
@@ -1204,8 +1212,13 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
 
     // flagging.py:967-969  flags |= time_flags; SumThreshold along frequency.
     // MAD per (time, chunk) = contiguous row segments of the TF layout.
-    rc = launch_u8<1>(r, ws.tflTF, ws.flagsTF, N, N, N, W);
-    if (rc) return rc;
+    if (defer_tf) {
+        hipLaunchKernelGGL(k_or_spec_more16, grid1(N / 16, W), dim3(256), 0, r.st, ws.flagsTF, ws.srows, ws.tflTF, T, Fa / 16);
+        LAUNCHCHK();
+    } else {
+        rc = launch_u8<1>(r, ws.tflTF, ws.flagsTF, N, N, N, W);
+        if (rc) return rc;
+    }
     rc = launch_median(r, residTF, ws.flagsTF, ws.med, N, N, (size_t)Fa, 1, ws.segC_start, ws.segC_len, T, G, W, pl.maxchunk, false, Fa % 4 == 0);
     if (rc) return rc;
     rc = launch_colst(r, pl.swF, residFT, ws.med, ws.fflFT, ws.d_chunk_ends, Fa, T, G, wsB, N, W);
@@ -1222,31 +1235,37 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
         HIPCHK(hipMemcpyAsync(r.dbg->u8 + Fa + N, ws.fflTF, N, hipMemcpyDeviceToDevice, r.st));
     }
 
-    // flagging.py:973  _combine_flags (time smearing)
+    // flagging.py:973  _combine_flags (time smearing), flagging.py:975  _unaverage_freq
+    // (replication, frequency smearing, counts)
     {
         int64_t e = p->time_extend;
         int64_t half = e >= 0 ? e / 2 : -((-e + 1) / 2);   // Python floor division
         int lo = (int)-half, hi = (int)(-half + e);
-        if (pl.vec)
-            hipLaunchKernelGGL(k_combine16, grid1(N / 16, W), dim3(256), 0, r.st, ws.srows, ws.tflTF, ws.fflTF, ws.comb, T, Fa / 16, lo, hi);
-        else
-            hipLaunchKernelGGL(k_combine, grid1(N, W), dim3(256), 0, r.st, ws.sout, ws.tflTF, ws.fflTF, ws.comb, T, Fa, Wn, lo, hi);
-        LAUNCHCHK();
-    }
-    // flagging.py:975  _unaverage_freq (replication, frequency smearing, counts)
-    {
-        int64_t e = p->freq_extend;
-        int64_t half = e >= 0 ? e / 2 : -((-e + 1) / 2);
-        int lo = (int)-half, hi = (int)(-half + e);
+        int64_t ef = p->freq_extend;
+        int64_t halff = ef >= 0 ? ef / 2 : -((-ef + 1) / 2);
+        int flo = (int)-halff, fhi = (int)(-halff + ef);
+        static const bool no_fuse = [] { const char* e = getenv("TRI_NO_FUSED_DILATE"); return e && e[0] == '1'; }();
         HIPCHK(hipMemsetAsync(ws.rowcnt, 0, (size_t)W * T * sizeof(int), r.st));
-        if (pl.vec && lo == -1 && hi == 2) {
+        if (pl.vec && flo == -1 && fhi == 2 && !no_fuse) {
+            // both smearings in one pass, no intermediate image
             dim3 grid((unsigned)cdiv(F / 16, 64), (unsigned)T, (unsigned)W);
-            hipLaunchKernelGGL((k_unaverage16<-1, 3>), grid, dim3(64), 0, r.st, ws.comb, ws.dil, ws.rowcnt, T, F / 16);
+            hipLaunchKernelGGL(k_combine_dilate16, grid, dim3(64), 0, r.st, ws.srows, ws.tflTF, ws.fflTF, ws.dil, ws.rowcnt, T, F / 16, lo, hi);
             hipLaunchKernelGGL(k_colcount, grid1(F / 4, W), dim3(256), 0, r.st, ws.dil, ws.colcnt, T, F / 4);
         } else {
-            HIPCHK(hipMemsetAsync(ws.colcnt, 0, (size_t)W * F * sizeof(int), r.st));
-            dim3 grid((unsigned)cdiv(F, 256), (unsigned)T, (unsigned)W);
-            hipLaunchKernelGGL(k_unaverage, grid, dim3(256), 0, r.st, ws.comb, ws.dil, ws.rowcnt, ws.colcnt, T, Fa, F, (int)pl.avg, lo, hi);
+            if (pl.vec)
+                hipLaunchKernelGGL(k_combine16, grid1(N / 16, W), dim3(256), 0, r.st, ws.srows, ws.tflTF, ws.fflTF, ws.comb, T, Fa / 16, lo, hi);
+            else
+                hipLaunchKernelGGL(k_combine, grid1(N, W), dim3(256), 0, r.st, ws.sout, ws.tflTF, ws.fflTF, ws.comb, T, Fa, Wn, lo, hi);
+            LAUNCHCHK();
+            if (pl.vec && flo == -1 && fhi == 2) {
+                dim3 grid((unsigned)cdiv(F / 16, 64), (unsigned)T, (unsigned)W);
+                hipLaunchKernelGGL((k_unaverage16<-1, 3>), grid, dim3(64), 0, r.st, ws.comb, ws.dil, ws.rowcnt, T, F / 16);
+                hipLaunchKernelGGL(k_colcount, grid1(F / 4, W), dim3(256), 0, r.st, ws.dil, ws.colcnt, T, F / 4);
+            } else {
+                HIPCHK(hipMemsetAsync(ws.colcnt, 0, (size_t)W * F * sizeof(int), r.st));
+                dim3 grid((unsigned)cdiv(F, 256), (unsigned)T, (unsigned)W);
+                hipLaunchKernelGGL(k_unaverage, grid, dim3(256), 0, r.st, ws.comb, ws.dil, ws.rowcnt, ws.colcnt, T, Fa, F, (int)pl.avg, flo, fhi);
+            }
         }
         LAUNCHCHK();
     }
