@@ -274,8 +274,17 @@ int tri_bench_sumthreshold(const float *data, const double *mad, uint8_t *out,
  *            positions each); `data` the amplitudes (n_win, n_col, n_line);
  *            out_o (n_win, n_col, n_line) receives |data - background|, out_w
  *            is scratch of the same size.
+ *   stage 2: the 1-D filter of the spectrum path (flagging.py:945-947 via
+ *            :516-579): n_win = 1, data (n_line, n_col) float32 with the line
+ *            axis = channel and one column per window of a batch, flags4 one
+ *            BYTE per sample (n_line, n_col); out_w / out_o (n_line, n_col)
+ *            receive the filtered weight and weight * data images, divided by
+ *            float32(2 r + 1) ** 4.
  * `variant`: 0 = the flagger's default route for this radius, 1 = LDS delay
  * lines only (K4b / K4c / multi-pass), 2 = register delay lines (K4r).
+ * For stage 2: 0 = default route, 1 = register delay lines (K4r), 2 / 3 = the
+ * stage pipeline across four waves (K4p) with blocks of 16 / 8 positions
+ * (TRI_EUNSUPPORTED when that block length does not apply to the shape).
  */
 int tri_bench_boxfilter(const float *data, const uint8_t *flags4, float *out_w,
                         float *out_o, int64_t n_win, int64_t n_line, int64_t n_col,

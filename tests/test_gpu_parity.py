@@ -81,6 +81,50 @@ def test_division_by_box_denominator(gpu):
     assert not bad, "inputs whose quotient differs from IEEE division, per radius: %s" % bad
 
 
+def _spectrum_filter(data, flags, radius, variant):
+    import ctypes as C
+    import torch
+    from tricolour_amd import _lib
+    n, c = data.shape
+    d = torch.from_numpy(np.ascontiguousarray(data, np.float32)).cuda()
+    f = torch.from_numpy(np.ascontiguousarray(flags, np.uint8)).cuda()
+    ow = torch.full((n, c), -7.0, dtype=torch.float32, device="cuda")
+    oo = torch.full((n, c), -7.0, dtype=torch.float32, device="cuda")
+    ms = C.c_float(0)
+    rc = _lib.lib().tri_bench_boxfilter(d.data_ptr(), f.data_ptr(), ow.data_ptr(), oo.data_ptr(), 1, n, c, radius,
+                                        2, variant, 1, C.byref(ms), None)
+    if rc != 0:
+        return None
+    torch.cuda.synchronize()
+    return ow.cpu().numpy(), oo.cpu().numpy()
+
+
+@pytest.mark.parametrize("shape,radius", [((96, 2), 8), ((96, 4), 8), ((200, 64), 8), ((333, 12), 21), ((1000, 8), 54),
+                                          ((1000, 6), 54), ((64, 130), 5), ((500, 1008), 32), ((40, 4), 43)])
+def test_spectrum_filter_routes(gpu, shape, radius):
+    """The 1-D box cascade of the spectrum path: register-ring kernel (variant 1) against the stage-pipelined
+    kernel with blocks of 16 and of 8 positions (variants 2, 3) and the flagger's own route (0) -- all four must
+    agree bit for bit, including NaN data under flags, lines shorter than the filter and ragged column counts."""
+    rs = np.random.RandomState(radius * 1000 + shape[0])
+    data = (rs.standard_normal(shape) * 3 + 10).astype(np.float32)
+    flags = rs.uniform(size=shape) < 0.1
+    flags[shape[0] // 2: shape[0] // 2 + 3 * radius, 0] = True     # a gap wider than the filter
+    data[flags & (rs.uniform(size=shape) < 0.3)] = np.nan
+    ref = _spectrum_filter(data, flags, radius, 1)
+    assert ref is not None
+    ran = 0
+    for variant in (0, 2, 3):
+        got = _spectrum_filter(data, flags, radius, variant)
+        if got is None:
+            continue                                                # that block length does not apply to this shape
+        ran += 1
+        for name, a, b in (("weights", ref[0], got[0]), ("data", ref[1], got[1])):
+            ok = _same_f32(a, b)
+            assert ok.all(), "variant %d, %s image: %d of %d words differ (first at %s)" % (
+                variant, name, (~ok).sum(), ok.size, np.argwhere(~ok)[0])
+    assert ran >= 1
+
+
 def test_random_windows_multi_batch(gpu, oracle):
     """Several windows, tiny workspace budget -> several internal batches."""
     import os
@@ -680,7 +724,7 @@ print("DIFF", bad)
 @pytest.mark.parametrize("knob", ["TRI_NO_AMPL_CACHE", "TRI_FILTER_NO_FUSED_DIV", "TRI_FILTER_NO_TIN", "TRI_FILTER_NO_LANE4",
                                   "TRI_NO_PACKED_FLAGS", "TRI_FILTER_MULTIPASS", "TRI_ST_GENERIC", "TRI_ST_REGISTER",
                                   "TRI_FILTER_DIRECT_FT", "TRI_FILTER_NO_REGRING", "TRI_FILTER_NO_REGRING_F", "TRI_MEDIAN_3PASS",
-                                  "TRI_NO_FUSED_REJECT", "TRI_NO_FT_SPEC_OR", "TRI_NO_FUSED_BEGIN", "TRI_NO_FUSED_DILATE"])
+                                  "TRI_NO_FUSED_REJECT", "TRI_NO_FT_SPEC_OR", "TRI_NO_FUSED_BEGIN", "TRI_NO_FUSED_DILATE", "TRI_SPEC_NO_PIPE"])
 def test_alternate_kernel_paths(gpu, knob):
     """Every fallback / A-B path selectable through an environment knob (read once
     per process, hence the subprocess) stays bit-exact against the oracle."""

@@ -1,0 +1,205 @@
+// Box-Gaussian cascade, stage-pipelined across the four waves of a workgroup.
+//
+// The register-ring kernels (kernels_boxline.hpp) give every wave all four
+// running sums of its 64 lines; with one wave per SIMD that is ~40 dependent-ish
+// instructions per position and the rings fill the whole register file.  Here a
+// workgroup of four waves (one per SIMD of a CU) shares 64 lines: wave s runs
+// ONLY stage s + 1, for every position, and hands its output to the next wave
+// through LDS.  Each stage's output stream lives in a circular LDS buffer that
+// is at once the FIFO to the next stage and that stage's delay line (the sample
+// that entered 2r positions ago is read back from the same buffer), so a
+// position costs a wave two LDS reads, one LDS write and the five arithmetic
+// instructions of one running sum:
+//     s += in[t];  out[t] = (V)s;  s -= in[t - 2r]       (float64 / int32 sums)
+// The arithmetic of every stage is the sequential recurrence of K4b, in the same
+// order -- results are bit-identical (flagging.py:389-419 per line).
+//
+// Schedule: positions are processed in blocks of B.  In iteration j every thread
+// helps staging block j from global memory into buffer 0 (prefetched P blocks
+// ahead in registers), wave s runs its stage over block j - s - 1, and every
+// thread helps storing block j - 5 of the last stage's output; one workgroup
+// barrier per iteration.  A circular buffer holds Lc >= 2r + 2B positions (a
+// multiple of B) plus a mirror of its first B positions after the end, so that
+// neither the B new inputs nor the B trailing ones of a block ever wrap: all
+// LDS addresses inside a block are static offsets from two registers.
+// Requires 2r >= B (a block never reads a trailing sample written in the block).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+// LDS bytes of one workgroup: four stage buffers + the double-buffered output block
+__host__ __device__ constexpr int boxp_lc(int r, int B) { return (2 * r + 2 * B + B - 1) / B * B; }
+__host__ __device__ constexpr size_t boxp_lds_bytes(int r, int B) {
+    return ((size_t)4 * (boxp_lc(r, B) + B) * 64 + (size_t)2 * B * 64) * 4;
+}
+
+// IMG 0: weight image (0/1 input, int32 sums); IMG 1: data image (flagged samples zeroed, float64 sums).
+// Byte flags [n][C], data [n][C], output [n][C] (one "window": the spectrum path).
+//
+// Global memory goes through buffer descriptors and every iteration issues the SAME vector-memory
+// instructions whatever the position (out-of-range accesses get an offset beyond the descriptor: loads
+// return 0, stores are dropped).  With no branch around them the compiler can count exactly how many
+// operations were issued after a prefetch and waits for that one only -- a branch would make it drain
+// the whole queue, i.e. expose the full memory latency in every iteration.
+// Host: C % (B / 4) == 0, n * C * 4 < 2^31, 2r >= B.
+template <int IMG, int B, int P>
+__device__ __forceinline__ void boxp_body(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags,
+                                          float* __restrict__ dst, const int n, const int C, const int r, const float denom) {
+    extern __shared__ float cf_ring[];
+    using V = typename std::conditional<IMG == 0, int, float>::type;
+    using A = typename std::conditional<IMG == 0, int, double>::type;
+    constexpr int K = B / 4;                                   // consecutive columns per thread when staging / storing
+    static_assert(K == 2 || K == 4, "block length 8 or 16");
+    constexpr unsigned OOB = 0x7ffffff0u;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int R2 = 2 * r;
+    const int Lc = boxp_lc(r, B), LcP = Lc + B;
+    V* bufs = reinterpret_cast<V*>(cf_ring);
+    float* outb = cf_ring + (size_t)4 * LcP * 64;
+    for (int k = tid; k < 4 * LcP * 64; k += 256) bufs[k] = 0;
+    const int NB = (n + 4 * r + B - 1) / B;                    // every stage runs over t in [0, n + 4r)
+
+    // staging / storing: thread -> row srow of a block, columns scol .. scol + K - 1
+    const int srow = tid / (64 / K);
+    const int scol = (tid % (64 / K)) * K;
+    const int gcol = blockIdx.x * 64 + scol;
+    const bool colok = gcol < C;                               // (C % K == 0: all K columns or none)
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void*)srcFlags, 0, (int)((unsigned)n * (unsigned)C), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, (int)((unsigned)n * (unsigned)C * 4u), 0x00020000);
+
+    unsigned pref[P];                                          // K flag bytes
+    float prex[IMG == 1 ? P : 1][K];
+    auto issue = [&](int blk, int q) {
+        const int t = blk * B + srow;
+        const unsigned e = (colok && t < n) ? (unsigned)t * (unsigned)C + (unsigned)gcol : OOB;   // element index
+        if (K == 4) pref[q] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(frs, (int)e, 0, 0);
+        else pref[q] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(frs, (int)e, 0, 0);
+        if (IMG == 1) {
+            // plain vector loads from a clamped address (hipcc 7.2 narrows __builtin_amdgcn_raw_buffer_load_b64 /
+            // _b128 results that are bit-cast to float to a ONE-dword load)
+            const float* a = srcData + ((colok && t < n) ? (size_t)e : (size_t)0);
+            if (K == 4) {
+                const float4 v = *reinterpret_cast<const float4*>(a);
+                prex[q][0] = v.x; prex[q][1] = v.y; prex[q][K - 2] = v.z; prex[q][K - 1] = v.w;
+            } else {
+                const float2 v = *reinterpret_cast<const float2*>(a);
+                prex[q][0] = v.x; prex[q][1] = v.y;
+            }
+        }
+    };
+    auto staged = [&](int blk, int q, int k) -> V {
+        const int t = blk * B + srow;
+        const bool fl = t >= n || !colok || ((pref[q] >> (8 * k)) & 0xFFu) != 0;    // beyond the line end: flagged
+        if (IMG == 0) return fl ? (V)0 : (V)1;
+        return fl ? (V)0 : (V)prex[IMG == 1 ? q : 0][k];
+    };
+#pragma unroll
+    for (int q = 0; q < P; q++) issue(q, q);
+
+    int lpin = 0;                                              // staging position in buffer 0
+    int pin = 0, pold = Lc - R2;                               // this wave's block position / trailing position
+    A acc = 0;
+    V* bin = bufs + (size_t)wave * LcP * 64 + lane;
+    V* bout = bufs + (size_t)(wave + 1) * LcP * 64 + lane;     // (wave 3 writes outb instead)
+    // a stage's output is masked where the NEXT stage does not take it (see boxline_step):
+    // stage 2 takes out_1[t] for t < n + 2r, stage 4 takes out_3[t] for t >= 2r
+    const int keep_lo = wave == 2 ? R2 : 0;
+    const int keep_hi = wave == 0 ? n + R2 : 0x7fffffff;
+    __syncthreads();
+
+    // NB + 5 iterations, rounded up to whole trips of P (the extra ones find nothing to do)
+    for (int j0 = 0; j0 < NB + 5; j0 += P) {
+#pragma unroll
+        for (int q = 0; q < P; q++) {
+            const int j = j0 + q;
+            if (j < NB) {                                      // stage block j (LDS only)
+                V* p = bufs + ((size_t)lpin + srow) * 64 + scol;
+                V sv[K];
+#pragma unroll
+                for (int k = 0; k < K; k++) sv[k] = staged(j, q, k);
+#pragma unroll
+                for (int k = 0; k < K; k++) p[k] = sv[k];
+                if (lpin == 0) {
+#pragma unroll
+                    for (int k = 0; k < K; k++) p[(size_t)Lc * 64 + k] = sv[k];
+                }
+                lpin = (lpin + B == Lc) ? 0 : lpin + B;
+            }
+            issue(j + P, q);                                   // fetch block j + P (always issued)
+            const int b = j - wave - 1;
+            if (b >= 0 && b < NB) {
+                const V* pi = bin + (size_t)pin * 64;
+                const V* po = bin + (size_t)pold * 64;
+                V xin[B], xold[B];
+#pragma unroll
+                for (int u = 0; u < B; u++) { xin[u] = pi[u * 64]; xold[u] = po[u * 64]; }
+                const int t0 = b * B;
+                if (wave == 3) {
+                    float* ob = outb + (size_t)(b & 1) * B * 64 + lane;
+#pragma unroll
+                    for (int u = 0; u < B; u++) {
+                        acc += (A)xin[u];
+                        ob[u * 64] = (float)acc;
+                        acc -= (A)xold[u];
+                    }
+                } else {
+                    V* po2 = bout + (size_t)pin * 64;
+                    const bool whole = t0 >= keep_lo && t0 + B <= keep_hi;
+                    V o[B];
+#pragma unroll
+                    for (int u = 0; u < B; u++) {
+                        acc += (A)xin[u];
+                        o[u] = (V)acc;
+                        acc -= (A)xold[u];
+                    }
+                    if (!whole) {
+                        asm volatile("" ::: "memory");          // (a real branch: interior blocks skip the masks)
+#pragma unroll
+                        for (int u = 0; u < B; u++) o[u] = (t0 + u >= keep_lo && t0 + u < keep_hi) ? o[u] : (V)0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < B; u++) po2[u * 64] = o[u];
+                    if (pin == 0) {
+#pragma unroll
+                        for (int u = 0; u < B; u++) po2[(Lc + u) * 64] = o[u];
+                    }
+                }
+                pin = (pin + B == Lc) ? 0 : pin + B;
+                pold = (pold + B >= Lc) ? pold + B - Lc : pold + B;
+            }
+            {                                                  // store block j - 5 (always issued)
+                const int bs = j - 5;
+                const int i = bs * B + srow - 4 * r;
+                const bool ok = bs >= 0 && bs < NB && i >= 0 && i < n && colok;
+                const float* ob = outb + ((size_t)(bs & 1) * B + srow) * 64 + scol;
+                const unsigned eb = ok ? ((unsigned)i * (unsigned)C + (unsigned)gcol) * 4u : OOB;
+                if (K == 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(ob);
+                    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                    u4 y;
+                    y[0] = __builtin_bit_cast(unsigned, v.x / denom); y[1] = __builtin_bit_cast(unsigned, v.y / denom);
+                    y[2] = __builtin_bit_cast(unsigned, v.z / denom); y[3] = __builtin_bit_cast(unsigned, v.w / denom);
+                    __builtin_amdgcn_raw_buffer_store_b128(y, ors, (int)eb, 0, 0);
+                } else {
+                    const float2 v = *reinterpret_cast<const float2*>(ob);
+                    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+                    u2 y;
+                    y[0] = __builtin_bit_cast(unsigned, v.x / denom); y[1] = __builtin_bit_cast(unsigned, v.y / denom);
+                    __builtin_amdgcn_raw_buffer_store_b64(y, ors, (int)eb, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// Spectrum path: grid (ceil(C / 64), 2 images), block 256, dynamic LDS boxp_lds_bytes(r, B)
+template <int B, int P>
+__global__ void __launch_bounds__(256, 1)
+k_boxp_spec(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags,
+            float* __restrict__ dstW, float* __restrict__ dstO, int n, int C, int r, float denom) {
+    if (blockIdx.y == 0) boxp_body<0, B, P>(srcData, srcFlags, dstW, n, C, r, denom);
+    else boxp_body<1, B, P>(srcData, srcFlags, dstO, n, C, r, denom);
+}

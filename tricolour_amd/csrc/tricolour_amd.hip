@@ -10,6 +10,7 @@
 #include "kernels_median.hpp"
 #include "kernels_boxfilter.hpp"
 #include "kernels_boxline.hpp"
+#include "kernels_boxpipe.hpp"
 #include "kernels_sumthreshold.hpp"
 
 // ===========================================================================
@@ -543,6 +544,30 @@ int launch_boxt_spec(const Run& r, int ks, const float* srcData, const uint8_t* 
     return set_err(TRI_EINVAL, "no register-ring kernel for %d slots", ks);
 }
 
+// Stage-pipelined form (kernels_boxpipe.hpp): block length B for radius rad, 0 when it does not apply
+// (2r >= B, four stage buffers within the CU's 160 KB of LDS).  TRI_SPEC_NO_PIPE=1 keeps the register rings.
+static thread_local int g_boxp_override = -1;   // tests / benches: 0 = off, 8 / 16 = only that block length
+static int boxp_pick_block(int rad, int C) {
+    static const bool off = [] { const char* e = getenv("TRI_SPEC_NO_PIPE"); return e && e[0] == '1'; }();
+    if (g_boxp_override == 0 || (off && g_boxp_override < 0)) return 0;
+    if (g_boxp_override != 8 && 2 * rad >= 16 && C % 4 == 0 && boxp_lds_bytes(rad, 16) <= 160 * 1024) return 16;
+    if (g_boxp_override == 16) return 0;
+    if (2 * rad >= 8 && C % 2 == 0 && boxp_lds_bytes(rad, 8) <= 160 * 1024) return 8;
+    return 0;
+}
+
+template <int B, int P>
+int launch_boxp_spec_b(const Run& r, const float* srcData, const uint8_t* srcFlags, float* dstW, float* dstO,
+                       int n, int C, int rad, float denom) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boxp_spec<B, P>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    HIPCHK(attr);
+    dim3 grid((unsigned)cdiv(C, 64), 2);
+    hipLaunchKernelGGL((k_boxp_spec<B, P>), grid, dim3(256), boxp_lds_bytes(rad, B), r.st, srcData, srcFlags, dstW, dstO, n, C, rad, denom);
+    LAUNCHCHK();
+    return TRI_OK;
+}
+
 int launch_boxt(const Run& r, int ks, const float* srcData, const uint8_t* srcFlags, float* dstW, float* dstO,
                 int n, int C, int rad, float denom, size_t sws, size_t dws, int64_t W) {
     switch (ks) {
@@ -563,6 +588,12 @@ int launch_colfilter(const Run& r, int srcmode, float* bufW, float* bufO, const 
     int bt = colfilter_lds_block(rad, C);
     if (deferred_denom) *deferred_denom = 0.0f;
     // spectrum path (one "window" of byte flags + data, both images): register-ring kernel from r = 4 on
+    if (srcmode == 0 && !deferred_denom && !transposed_out && weights_are_01 && W == 1 && boxp_pick_block(rad, C) > 0 && rad <= 107 &&
+        (uint64_t)n * (uint64_t)C * 4u < (1ull << 31) && ((uintptr_t)srcData % 16 == 0) && ((uintptr_t)srcFlags % 4 == 0) &&
+        ((uintptr_t)dstW % 16 == 0) && ((uintptr_t)dstO % 16 == 0)) {
+        if (boxp_pick_block(rad, C) == 16) return launch_boxp_spec_b<16, 16>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom);
+        return launch_boxp_spec_b<8, 16>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom);
+    }
     if (srcmode == 0 && !deferred_denom && !transposed_out && weights_are_01 && W == 1 && boxr_pick_ks(rad) > 0 &&
         (uint64_t)n * (uint64_t)C * 4u < (1ull << 31))
         return launch_boxt_spec(r, boxr_pick_ks(rad), srcData, srcFlags, dstW, dstO, n, C, rad, denom);
@@ -1604,10 +1635,11 @@ extern "C" int tri_bench_boxfilter(const float* data, const uint8_t* flags4, flo
                                    int64_t n_win, int64_t n_line, int64_t n_col, int64_t radius,
                                    int stage, int variant, int repeats, float* ms_per_launch, void* stream) {
     if (!data || !flags4 || !out_w || !out_o || !ms_per_launch) return set_err(TRI_EINVAL, "NULL pointer argument");
-    if (n_win <= 0 || n_line <= 0 || n_col <= 0 || repeats <= 0 || n_win > 65535 || radius <= 0 || n_line % 4 != 0)
+    if (n_win <= 0 || n_line <= 0 || n_col <= 0 || repeats <= 0 || n_win > 65535 || radius <= 0 || (stage != 2 && n_line % 4 != 0))
         return set_err(TRI_EINVAL, "bad shape");
-    if (stage != 0 && stage != 1) return set_err(TRI_EUNSUPPORTED, "stage must be 0 or 1");
-    if (variant < 0 || variant > 2) return set_err(TRI_EINVAL, "variant must be 0, 1 or 2");
+    if (stage < 0 || stage > 2) return set_err(TRI_EUNSUPPORTED, "stage must be 0, 1 or 2");
+    if (variant < 0 || variant > 3) return set_err(TRI_EINVAL, "variant must be 0 .. 3");
+    if (stage == 2 && n_win != 1) return set_err(TRI_EINVAL, "the spectrum stage takes one window");
     Run r;
     r.st = (hipStream_t)stream;
     r.p = nullptr;
@@ -1617,10 +1649,16 @@ extern "C" int tri_bench_boxfilter(const float* data, const uint8_t* flags4, flo
     HIPCHK(hipEventCreate(&e1));
     const size_t N = (size_t)n_line * n_col;
     g_boxr_override = variant == 0 ? -1 : (variant == 1 ? 0 : 1);
+    // stage 2: 0 = the flagger's route, 1 = register rings, 2 / 3 = stage pipeline with blocks of 16 / 8
+    if (stage == 2) { g_boxr_override = -1; g_boxp_override = variant == 0 ? -1 : (variant == 1 ? 0 : (variant == 2 ? 16 : 8)); }
     int rc = TRI_OK;
     HIPCHK(hipEventRecord(e0, r.st));
     for (int i = 0; i < repeats && rc == TRI_OK; i++) {
-        if (stage == 0) {
+        if (stage == 2) {
+            // spectrum path: byte flags [n_line][n_col] + data -> filtered weight and data images
+            if (variant >= 2 && boxp_pick_block((int)radius, (int)n_col) == 0) rc = set_err(TRI_EUNSUPPORTED, "no stage pipeline for this shape");
+            else rc = launch_colfilter(r, 0, out_w, out_o, data, flags4, out_w, out_o, (int)n_line, (int)n_col, (int)radius, 0, 0, 0, 1, nullptr, false, true);
+        } else if (stage == 0) {
             rc = launch_colfilter(r, 2, out_w, out_o, data, flags4, out_w, out_o, (int)n_line, (int)n_col, (int)radius, N, N, N,
                                   n_win, nullptr, false, true);
         } else {
@@ -1645,6 +1683,7 @@ extern "C" int tri_bench_boxfilter(const float* data, const uint8_t* flags4, flo
         }
     }
     g_boxr_override = -1;
+    g_boxp_override = -1;
     if (rc) return rc;
     HIPCHK(hipEventRecord(e1, r.st));
     HIPCHK(hipEventSynchronize(e1));
