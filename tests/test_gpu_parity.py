@@ -125,6 +125,25 @@ def test_spectrum_filter_routes(gpu, shape, radius):
     assert ran >= 1
 
 
+def test_interpolation_across_segments(gpu, oracle):
+    """Background NaNs (weight 0 under wide flagged bands) are repaired per 512-channel segment: bands that
+    start a line, end it, span several segments or a whole line must come out as the one-thread-per-line walk
+    (and the oracle) has them, in the 2-D background and in the median spectrum alike."""
+    rs = np.random.RandomState(77)
+    shape = (3, 1, 16, 2048)
+    vis = (rs.standard_normal(shape) + 1j * rs.standard_normal(shape)).astype(np.complex64) * 2 + 5
+    flags = rs.uniform(size=shape) < 0.02
+    flags[..., 0:40] = True            # band at the start of every line
+    flags[..., 400:1300] = True        # spans two segment boundaries
+    flags[..., 1530:1545] = True       # short band just across a boundary (1536)
+    flags[..., 2000:2048] = True       # band at the end
+    flags[1, 0, 3, :] = True           # a fully flagged time row
+    flags[2] = True                    # a fully flagged window
+    vis[0, 0, 5, 700] = np.nan
+    kw = dict(num_major_iterations=2, spike_width_freq=6.0, spike_width_time=3.0, freq_chunks=4)
+    _compare(gpu, oracle, vis, flags, kw, "segmented interpolation")
+
+
 def test_random_windows_multi_batch(gpu, oracle):
     """Several windows, tiny workspace budget -> several internal batches."""
     import os
@@ -724,7 +743,7 @@ print("DIFF", bad)
 @pytest.mark.parametrize("knob", ["TRI_NO_AMPL_CACHE", "TRI_FILTER_NO_FUSED_DIV", "TRI_FILTER_NO_TIN", "TRI_FILTER_NO_LANE4",
                                   "TRI_NO_PACKED_FLAGS", "TRI_FILTER_MULTIPASS", "TRI_ST_GENERIC", "TRI_ST_REGISTER",
                                   "TRI_FILTER_DIRECT_FT", "TRI_FILTER_NO_REGRING", "TRI_FILTER_NO_REGRING_F", "TRI_MEDIAN_3PASS",
-                                  "TRI_NO_FUSED_REJECT", "TRI_NO_FT_SPEC_OR", "TRI_NO_FUSED_BEGIN", "TRI_NO_FUSED_DILATE", "TRI_SPEC_NO_PIPE"])
+                                  "TRI_NO_FUSED_REJECT", "TRI_NO_FT_SPEC_OR", "TRI_NO_FUSED_BEGIN", "TRI_NO_FUSED_DILATE", "TRI_SPEC_NO_PIPE", "TRI_INTERP_ONE_PASS"])
 def test_alternate_kernel_paths(gpu, knob):
     """Every fallback / A-B path selectable through an environment knob (read once
     per process, hence the subprocess) stays bit-exact against the oracle."""

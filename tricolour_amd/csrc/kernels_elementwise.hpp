@@ -268,6 +268,106 @@ __global__ void k_colinterp(float* __restrict__ a, int L, int C, size_t ws,
     }
 }
 
+// K6p: the same interpolation with the line cut into segments of INTERP_SEG positions that are
+// repaired independently (a line of an SKA-sized window is 65536 channels long and there may be
+// only a few hundred lines: one thread per line is a long, latency-bound walk).
+//   k_interp_scan: per (segment, line) the first and the last valid position and whether any NaN
+//   k_interp_fix : repairs the NaNs of a segment; the valid neighbours of runs that touch its ends
+//                  come from the table (valid samples are never rewritten, NaNs only by their own
+//                  segment's thread, so there is no ordering between segments)
+// Every repaired value is computed by k_colinterp's expressions from the same (last valid, next
+// valid) pair -- identical results.  The residual data - background is redone only where the
+// background was repaired.  tab: int [W][nseg][3][C].  grid (ceil(C/64), nseg, W), block 64
+#define INTERP_SEG 512
+__global__ void k_interp_scan(const float* __restrict__ a, int L, int C, size_t ws, const uint8_t* __restrict__ nanflag,
+                              int* __restrict__ tab) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    const int seg = blockIdx.y, nseg = gridDim.y;
+    const int s0 = seg * INTERP_SEG, s1 = min(L, s0 + INTERP_SEG);
+    int* t = tab + (((size_t)blockIdx.z * nseg + seg) * 3) * C + c;
+    if (nanflag && !nanflag[(size_t)blockIdx.z * C + c]) {   // no NaN anywhere in this line
+        t[0] = s0; t[C] = s1 - 1; t[2 * (size_t)C] = 0;
+        return;
+    }
+    const float* x = a + (size_t)blockIdx.z * ws + c;
+    const size_t Cs = (size_t)C;
+    int first = -1, last = -1, nans = 0;
+    constexpr int PFI = 64;
+    for (int i0 = s0; i0 < s1; i0 += PFI) {
+        float vv[PFI];
+#pragma unroll
+        for (int u = 0; u < PFI; u++) vv[u] = (i0 + u < s1) ? x[(size_t)(i0 + u) * Cs] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < PFI; u++) {
+            const bool nn = isnan(vv[u]);                      // (padding beyond s1 is valid-looking but not counted)
+            if (i0 + u < s1) {
+                if (nn) nans = 1;
+                else { if (first < 0) first = i0 + u; last = i0 + u; }
+            }
+        }
+    }
+    t[0] = first; t[C] = last; t[2 * (size_t)C] = nans;
+}
+
+__global__ void k_interp_fix(float* __restrict__ a, int L, int C, size_t ws, const int* __restrict__ tab,
+                             const float* __restrict__ data, size_t ws_data, float* __restrict__ resid) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    const int seg = blockIdx.y, nseg = gridDim.y;
+    const int* tw = tab + (size_t)blockIdx.z * nseg * 3 * C + c;   // entry (sg, k) at (sg * 3 + k) * C
+    if (!tw[((size_t)seg * 3 + 2) * C]) return;                  // nothing to repair here
+    const int s0 = seg * INTERP_SEG, s1 = min(L, s0 + INTERP_SEG);
+    float* x = a + (size_t)blockIdx.z * ws + c;
+    const float* d = resid ? data + (size_t)blockIdx.z * ws_data + c : nullptr;
+    float* rr = resid ? resid + (size_t)blockIdx.z * ws + c : nullptr;
+    const size_t Cs = (size_t)C;
+    auto put = [&](int j, float v) {
+        x[(size_t)j * Cs] = v;
+        if (resid) rr[(size_t)j * Cs] = d[(size_t)j * Cs] - v;
+    };
+    // positions [lo, hi) between the valid samples (last, lastv) and (i, v); last < 0: none before
+    auto fill = [&](int lo, int hi, int last, float lastv, int i, float v) {
+        if (last < 0) {
+            for (int j = lo; j < hi; j++) put(j, v);             // extrapolate backwards
+        } else {
+            float diff = v - lastv;
+            double grad = (double)diff / (double)(i - last);
+            for (int j = lo; j < hi; j++) put(j, (float)((double)lastv + (double)(j - last) * grad));
+        }
+    };
+    int last = -1;
+    for (int sg = seg - 1; sg >= 0 && last < 0; sg--) last = tw[((size_t)sg * 3 + 1) * C];
+    float lastv = last >= 0 ? x[(size_t)last * Cs] : 0.0f;
+    int run = s0;
+    constexpr int PFI = 64;
+    for (int i0 = s0; i0 < s1; i0 += PFI) {
+        float vv[PFI];
+#pragma unroll
+        for (int u = 0; u < PFI; u++) vv[u] = (i0 + u < s1) ? x[(size_t)(i0 + u) * Cs] : NAN;
+#pragma unroll
+        for (int u = 0; u < PFI; u++) {
+            const int i = i0 + u;
+            const float v = vv[u];
+            if (i >= s1 || isnan(v)) continue;
+            if (run < i) fill(run, i, last, lastv, i, v);
+            last = i;
+            lastv = v;
+            run = i + 1;
+        }
+    }
+    if (run < s1) {                                              // the run continues into the next segments
+        int nxt = -1;
+        for (int sg = seg + 1; sg < nseg && nxt < 0; sg++) nxt = tw[((size_t)sg * 3) * C];
+        if (nxt >= 0) {
+            fill(run, s1, last, lastv, nxt, x[(size_t)nxt * Cs]);
+        } else {
+            const float f = last < 0 ? 0.0f : lastv;             // all NaN -> zeros; else extrapolate forwards
+            for (int j = run; j < s1; j++) put(j, f);
+        }
+    }
+}
+
 // out = a - b  (flagging.py:950, 962)
 __global__ void k_sub(const float* __restrict__ a, const float* __restrict__ b,
                       float* __restrict__ out, size_t nper, size_t ws_a, size_t ws_b,

@@ -151,6 +151,7 @@ struct Ws {
     float *sdata, *sw, *so, *sres;
     uint8_t *sflags, *sbgf, *sout, *srows;   // srows: sout as rows [Wb][Fa]
     uint16_t* nanmask;                       // cached-amplitude path: one NaN bit per sample, 16 samples per word
+    int* itab;                               // segment table of the interpolation (K6p)
     float* srowsf;                           // spectrum residuals as rows [Wb][Fa] (median input)
     uint8_t* srowsu;                         // their flags as rows
     double* smed;     // [Wb][G]
@@ -202,6 +203,7 @@ static void carve(const Plan& pl, int64_t Wb, void* base, size_t cap, bool dry, 
     ws->rowcnt = b.get<int>(W * T);
     ws->colcnt = b.get<int>(W * F);
     ws->nanmask = b.get<uint16_t>(W * N / 16 + 8);
+    ws->itab = b.get<int>(3 * W * (size_t)cdiv(Fa, INTERP_SEG) * std::max<size_t>(T, 1));
     ws->med = b.get<double>(W * std::max(Fa, T * G));
     size_t PS = (size_t)pl.PF;  // spectrum padded length
     ws->sdata = b.get<float>(Fa * W);
@@ -722,6 +724,22 @@ int launch_colst(const Run& r, const StWin& sw, const float* data, const double*
     return TRI_OK;
 }
 
+// _linearly_interpolate_nans1d along the line axis of [L][C] images (K6 / K6p)
+int launch_interp(const Run& r, float* a, int L, int C, size_t ws, int64_t W, const uint8_t* nanflag,
+                  const float* data, size_t ws_data, float* resid) {
+    static const bool one_pass = [] { const char* e = getenv("TRI_INTERP_ONE_PASS"); return e && e[0] == '1'; }();
+    const int nseg = (int)cdiv(L, INTERP_SEG);
+    if (one_pass || nseg < 2 || nseg > 65535) {
+        hipLaunchKernelGGL(k_colinterp, dim3((unsigned)cdiv(C, 256), (unsigned)W), dim3(256), 0, r.st, a, L, C, ws, nanflag, data, ws_data, resid);
+    } else {
+        dim3 grid((unsigned)cdiv(C, 64), (unsigned)nseg, (unsigned)W);
+        hipLaunchKernelGGL(k_interp_scan, grid, dim3(64), 0, r.st, (const float*)a, L, C, ws, nanflag, r.ws.itab);
+        hipLaunchKernelGGL(k_interp_fix, grid, dim3(64), 0, r.st, a, L, C, ws, (const int*)r.ws.itab, data, ws_data, resid);
+    }
+    LAUNCHCHK();
+    return TRI_OK;
+}
+
 template <typename T>
 int launch_transpose(const Run& r, const T* src, T* dst, int R, int C, size_t sws, size_t dws,
                      int64_t W, float denom = 0.0f) {
@@ -962,9 +980,7 @@ int spectrum_background(const Run& r) {
             LAUNCHCHK();
         }
     }
-    hipLaunchKernelGGL(k_colinterp, dim3((unsigned)cdiv(Wn, 256), 1), dim3(256), 0, r.st, ws.so, Fa, Wn, (size_t)0, (const uint8_t*)nullptr, (const float*)nullptr, (size_t)0, (float*)nullptr);
-    LAUNCHCHK();
-    return TRI_OK;
+    return launch_interp(r, ws.so, Fa, Wn, (size_t)0, 1, (const uint8_t*)nullptr, (const float*)nullptr, (size_t)0, (float*)nullptr);
 }
 
 // _get_background2d (flagging.py:516-579) for every window of the batch.
@@ -1129,9 +1145,7 @@ int background2d(const Run& r, bool flagsFT_current) {
             if (rc) return rc;
         }
     }
-    hipLaunchKernelGGL(k_colinterp, dim3((unsigned)cdiv(T, 256), (unsigned)W), dim3(256), 0, r.st, ws.Bo, Fa, T, wsB, reinterpret_cast<const uint8_t*>(ws.rowcnt), (const float*)ws.dataFT, N, ws.Bw);
-    LAUNCHCHK();
-    return TRI_OK;
+    return launch_interp(r, ws.Bo, Fa, T, wsB, W, reinterpret_cast<const uint8_t*>(ws.rowcnt), (const float*)ws.dataFT, N, ws.Bw);
 }
 
 // One major iteration (_get_flags_impl, flagging.py:745-781) for a batch.
