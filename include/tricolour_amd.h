@@ -313,7 +313,10 @@ int tri_sum_threshold_flagger_debug(const void *vis, int vis_dtype,
  * 1 = wave kernel, 2 / 3 = three-pass workgroup kernel with scalar / vector loads,
  * 5 / 6 = two-pass workgroup kernel with vector / scalar loads, 7 = two-pass
  * kernel, vector loads over segments that need not be 4-aligned (row_len % 4 == 0),
- * 8 = multi-workgroup two-pass select (one segment spanning the row).
+ * 8 = multi-workgroup two-pass select (one segment spanning the row),
+ * 9 / 10 = the two-pass select with the predicted-bin candidate window in
+ * global scratch (one read of the segment when the prediction holds;
+ * 9 vector loads, 10 scalar).
  * Restates _median_abs / _median_abs_axis0 (flagging.py:267-304).
  */
 int tri_test_median(const float *data, const uint8_t *flags, double *med,

@@ -325,7 +325,10 @@ def _np_median_abs(vals):
     (3, 40000, [0, 3999, 4001, 26214, 40000], (6, 7)),      # two-pass kernel, vector loads, segments that start / end inside a 16-byte group
     (2, 8, [0, 1, 3, 8], (7,)),
     (2, 1 << 20, [0, 1 << 20], (8, 5)),                     # multi-workgroup select (16 slices per row)
-    (3, 70001, [0, 70001], (8,)),                           # ... scalar loads, ragged last slice
+    (3, 70001, [0, 70001], (8, 10)),                        # ... scalar loads, ragged last slice
+    (1, 300000, [0, 100000, 300000], (9, 10)),              # predicted candidate window (hits, misses on the odd rows)
+    (2, 1 << 20, [0, 1 << 20], (9,)),
+    (3, 419432, [0, 8, 65544, 419432], (9, 10)),            # short / just-long-enough / block-median-sized segments
 ])
 def test_median_kernels(gpu, rows, row_len, ends, variants):
     import ctypes as C
@@ -743,7 +746,7 @@ print("DIFF", bad)
 @pytest.mark.parametrize("knob", ["TRI_NO_AMPL_CACHE", "TRI_FILTER_NO_FUSED_DIV", "TRI_FILTER_NO_TIN", "TRI_FILTER_NO_LANE4",
                                   "TRI_NO_PACKED_FLAGS", "TRI_FILTER_MULTIPASS", "TRI_ST_GENERIC", "TRI_ST_REGISTER",
                                   "TRI_FILTER_DIRECT_FT", "TRI_FILTER_NO_REGRING", "TRI_FILTER_NO_REGRING_F", "TRI_MEDIAN_3PASS",
-                                  "TRI_NO_FUSED_REJECT", "TRI_NO_FT_SPEC_OR", "TRI_NO_FUSED_BEGIN", "TRI_NO_FUSED_DILATE", "TRI_SPEC_NO_PIPE", "TRI_INTERP_ONE_PASS"])
+                                  "TRI_NO_FUSED_REJECT", "TRI_NO_FT_SPEC_OR", "TRI_NO_FUSED_BEGIN", "TRI_NO_FUSED_DILATE", "TRI_SPEC_NO_PIPE", "TRI_INTERP_ONE_PASS", "TRI_MEDIAN_NO_PREDICT"])
 def test_alternate_kernel_paths(gpu, knob):
     """Every fallback / A-B path selectable through an environment knob (read once
     per process, hence the subprocess) stays bit-exact against the oracle."""

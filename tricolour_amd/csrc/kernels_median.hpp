@@ -206,6 +206,9 @@ k_median(const float* __restrict__ data, const uint8_t* __restrict__ flags,
 // segments themselves may start and end anywhere)
 // ---------------------------------------------------------------------------
 #define SEL2_CAND 4096
+#ifndef MED2_WIN
+#define MED2_WIN 24u                 // half-width (bins) of the candidate window around the predicted bin (K3c with prediction)
+#endif
 #ifndef MED2_UNROLL
 #define MED2_UNROLL 4          // 16-byte groups in flight per thread
 #endif
@@ -308,11 +311,11 @@ __global__ void __launch_bounds__(256)
 k_median2(const float* __restrict__ data, const uint8_t* __restrict__ flags,
           double* __restrict__ med, size_t WSd, size_t WSf, size_t RS, size_t ES,
           const int64_t* __restrict__ seg_start, const int64_t* __restrict__ seg_len,
-          int R, int G) {
+          int R, int G, unsigned* __restrict__ gcand = nullptr, size_t cand_ws = 0, unsigned cand_cap = 0) {
     __shared__ unsigned hist[SEL_BINS];
     __shared__ unsigned cand[SEL2_CAND];
     __shared__ unsigned sh[9];
-    __shared__ unsigned sh_lo, sh_hi, sh_bin, sh_exc, sh_ncand, sh_below1, sh_mode;
+    __shared__ unsigned sh_lo, sh_hi, sh_bin, sh_exc, sh_ncand, sh_below1, sh_mode, sh_excw;
     const int seg = blockIdx.x;
     const int row = seg / G, g = seg % G;
     const size_t win = blockIdx.y;
@@ -424,13 +427,10 @@ k_median2(const float* __restrict__ data, const uint8_t* __restrict__ flags,
         return b > 2047u ? 2047u : b;
     };
 
-    // ---- pass 1: histogram of every unflagged key ----
-#pragma unroll
-    for (int u = 0; u < SEL_BINS / 256; u++) hist[u * 256 + tid] = 0;
-    __syncthreads();
-    if (hi >= lo) enumerate_all([&](unsigned k) { atomicAdd(&hist[bin_of(k)], 1u); });
-    __syncthreads();
-    if (hi >= lo) {
+    // Bin holding rank total / 2 of the histogram in LDS -> sh_bin, keys below it -> sh_exc, per-wave
+    // totals -> sh[0..3]; also the number of keys below bin `wlo` -> sh_excw.  Returns this thread's count
+    // of the selected bin when it owns it (else 0) through sh_mode's caller.  (All threads; two barriers.)
+    auto locate = [&](unsigned wlo) -> unsigned {
         unsigned v[8];
         uint4 q0 = reinterpret_cast<const uint4*>(hist)[2 * tid];
         uint4 q1 = reinterpret_cast<const uint4*>(hist)[2 * tid + 1];
@@ -456,6 +456,13 @@ k_median2(const float* __restrict__ data, const uint8_t* __restrict__ flags,
         }
         const unsigned kk = total >> 1;
         const unsigned exc = woff + inc - sacc;
+        if ((unsigned)tid == (wlo >> 3)) {
+            unsigned c = exc;
+#pragma unroll
+            for (int q = 0; q < 7; q++)
+                if ((unsigned)q < (wlo & 7u)) c += v[q];
+            sh_excw = c;
+        }
         if (total > 0 && kk >= exc && kk < exc + sacc) {
             unsigned c = exc;
             int j = 0;
@@ -469,18 +476,87 @@ k_median2(const float* __restrict__ data, const uint8_t* __restrict__ flags,
             sh_mode = (b >= 1 && b <= 2046 && v[j] <= SEL2_CAND) ? 1u : 0u;
         }
         __syncthreads();
+        return total;
+    };
+
+    // ---- pass 0b (callers with a candidate buffer): PREDICT the bin of the median from 64 runs of 256
+    // consecutive samples (4 % of the segment, coalesced).  Pass 1 then also appends every key within
+    // MED2_WIN bins of the prediction to the candidate buffer in global memory (~7 % of the keys); when the
+    // true bin -- known once the histogram is complete -- lies inside that window, the exact select runs on
+    // the candidates and the segment has been read ONCE.  A miss costs the second pass it always used to.
+    bool predict = gcand != nullptr && hi >= lo && len >= 65536 && ES == 1;
+    unsigned wlo = 1, whi = 0;
+    if (predict) {
+#pragma unroll
+        for (int u = 0; u < SEL_BINS / 256; u++) hist[u * 256 + tid] = 0;
+        __syncthreads();
+        const int64_t rstep = len / 64;
+#pragma unroll 8
+        for (int rr = 0; rr < 64; rr++) {
+            const int64_t i = rr * rstep + tid;
+            if (!flags[i]) atomicAdd(&hist[bin_of(__float_as_uint(data[i]) & 0x7FFFFFFFu)], 1u);
+        }
+        __syncthreads();
+        const unsigned ns = locate(1);
+        const unsigned bp = sh_bin;
+        predict = ns >= 4096;                                    // (uniform) too few unflagged samples: no prediction
+        if (predict) {
+            wlo = bp > MED2_WIN + 1u ? bp - MED2_WIN : 1u;
+            whi = bp + MED2_WIN < 2046u ? bp + MED2_WIN : 2046u;
+        }
+        __syncthreads();
+        if (tid == 0) sh_mode = 0;
     }
-    if (sh_mode == 0) {
+    gcand += win * cand_ws + (size_t)seg * cand_cap;
+
+    // ---- pass 1: histogram of every unflagged key ----
+#pragma unroll
+    for (int u = 0; u < SEL_BINS / 256; u++) hist[u * 256 + tid] = 0;
+    __syncthreads();
+    if (predict) {
+        unsigned mb1 = 0;
+        const unsigned wspan = whi - wlo;
+        enumerate_all([&](unsigned k) {
+            const unsigned b = bin_of(k);
+            atomicAdd(&hist[b], 1u);
+            if (b - wlo <= wspan) {
+                const unsigned pos = atomicAdd(&sh_ncand, 1u);
+                if (pos < cand_cap) gcand[pos] = k;
+            } else if (b < wlo) {
+                mb1 = max(mb1, k + 1);
+            }
+        });
+        mb1 = wave_max_u32(mb1);
+        if (lane == 0 && mb1) atomicMax(&sh_below1, mb1);
+        __threadfence_block();
+    } else if (hi >= lo) {
+        enumerate_all([&](unsigned k) { atomicAdd(&hist[bin_of(k)], 1u); });
+    }
+    __syncthreads();
+    unsigned total = 0;
+    if (hi >= lo) total = locate(wlo);
+    if (sh_mode == 0 && !(predict && sh_bin >= wlo && sh_bin <= whi && sh_ncand <= cand_cap)) {
         // nothing sampled, empty segment, end bin or overfull bin: three passes over the segment
         const Sel3State st = select3(hist, sh, enumerate_all, -1);
         finish(st, 1);
         return;
     }
+    if (predict && sh_bin >= wlo && sh_bin <= whi && sh_ncand <= cand_cap) {
+        // the window holds the median: exact select of rank (n/2 - keys below the window) among its keys
+        const unsigned nc = sh_ncand, excw = sh_excw, below1 = sh_below1;
+        __syncthreads();   // sh[] is reused by select3 below
+        auto enumerate_gc = [&](auto&& visit) {
+            for (unsigned i = tid; i < nc; i += 256) visit(gcand[i]);
+        };
+        Sel3State st = select3(hist, sh, enumerate_gc, (long long)((total >> 1) - excw));
+        st.n = total;
+        finish(st, below1);
+        return;
+    }
     const unsigned bsel = sh_bin, exc = sh_exc;
-    unsigned total = 0;
-#pragma unroll
-    for (int w2 = 0; w2 < 4; w2++) total += sh[w2];
-    __syncthreads();   // sh[] is reused by select3 below
+    __syncthreads();   // sh[] is reused by select3 below; restart the counters the prediction may have used
+    if (tid == 0) { sh_ncand = 0; sh_below1 = 0; }
+    __syncthreads();
 
     // ---- pass 2: compact the selected bin's keys, largest key of the lower bins ----
     {

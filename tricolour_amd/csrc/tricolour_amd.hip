@@ -380,7 +380,8 @@ bool st_use_mask(int L, int C) {
 int launch_median(const Run& r, const float* data, const uint8_t* flags, double* med, size_t WSd,
                   size_t WSf, size_t RS, size_t ES, const int64_t* seg_start,
                   const int64_t* seg_len, int R, int G, int64_t W, int64_t max_len, bool vec_ok = false,
-                  bool rows_aligned = false, bool segs_aligned = false) {
+                  bool rows_aligned = false, bool segs_aligned = false,
+                  unsigned* gcand = nullptr, size_t cand_ws = 0, unsigned cand_cap = 0) {
     if ((int64_t)R * G <= 0 || W <= 0) return TRI_OK;
     if ((int64_t)R * G > 0x7FFFFFFF || W > 65535) return set_err(TRI_EUNSUPPORTED, "median grid too large");
     // segments of contiguous 4-aligned rows can be loaded 16 bytes at a time
@@ -408,10 +409,15 @@ int launch_median(const Run& r, const float* data, const uint8_t* flags, double*
             hipLaunchKernelGGL(k_median<true>, grid, dim3(256), 0, r.st, data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
         else if (three)
             hipLaunchKernelGGL(k_median<false>, grid, dim3(256), 0, r.st, data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
-        else if (vec_ok || row4)
-            hipLaunchKernelGGL(k_median2<true>, grid, dim3(256), 0, r.st, data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
-        else
-            hipLaunchKernelGGL(k_median2<false>, grid, dim3(256), 0, r.st, data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
+        else {
+            // scratch for the predicted-window candidates (K3c): one read of the segment instead of two
+            static const bool no_predict = [] { const char* e = getenv("TRI_MEDIAN_NO_PREDICT"); return e && e[0] == '1'; }();
+            if (no_predict || cand_cap < max_len) { gcand = nullptr; cand_ws = 0; cand_cap = 0; }
+            if (vec_ok || row4)
+                hipLaunchKernelGGL(k_median2<true>, grid, dim3(256), 0, r.st, data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G, gcand, cand_ws, cand_cap);
+            else
+                hipLaunchKernelGGL(k_median2<false>, grid, dim3(256), 0, r.st, data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G, gcand, cand_ws, cand_cap);
+        }
     }
     LAUNCHCHK();
     return TRI_OK;
@@ -1122,8 +1128,10 @@ int background2d(const Run& r, bool flagsFT_current) {
                 if (rc) return rc;
             }
             // block medians over (all times) x (chunk channels): contiguous in FT
+            // (the time stage's images in ws.Aw / ws.Ao are dead here: candidate scratch, wsA / G keys per block)
             rc = launch_median(r, ws.Bo, ws.bgfFT, ws.med, wsB, N, 0, 1, ws.segB_start, ws.segB_len, 1, G, W, pl.maxchunk * pl.T,
-                               T % 4 == 0 && wsB % 4 == 0 && N % 4 == 0);
+                               T % 4 == 0 && wsB % 4 == 0 && N % 4 == 0, false, false,
+                               reinterpret_cast<unsigned*>(ws.Aw), wsA, (unsigned)std::min<size_t>(wsA / (size_t)G, 0x7fffffffu));
             if (rc) return rc;
             static const bool no_fuse = [] { const char* e = getenv("TRI_NO_FUSED_REJECT"); return e && e[0] == '1'; }();
             if (r.pl.vec && wsB % 4 == 0 && packed && !no_fuse) {
@@ -1811,7 +1819,24 @@ extern "C" int tri_test_median(const float* data, const uint8_t* flags, double* 
     else if (variant == 5)
         hipLaunchKernelGGL(k_median2<true>, dim3((unsigned)(R * G), (unsigned)n_win), dim3(256), 0, st, data, flags,
                            med, WS, WS, RS, (size_t)1, d_start, d_len, R, G);
-    else if (variant == 7) {
+    else if (variant == 9 || variant == 10) {
+        // K3c with the predicted-window candidates in global scratch (9: vector loads, 10: scalar)
+        if (variant == 9 && row_len % 4 != 0) return set_err(TRI_EINVAL, "variant 9 needs row_len % 4 == 0");
+        unsigned* gc = nullptr;
+        const size_t cap = (size_t)maxlen, per_win = cap * (size_t)R * G;
+        HIPCHK(hipMalloc(&gc, per_win * (size_t)n_win * sizeof(unsigned)));
+        if (variant == 9)
+            hipLaunchKernelGGL(k_median2<true>, dim3((unsigned)(R * G), (unsigned)n_win), dim3(256), 0, st, data, flags,
+                               med, WS, WS, RS, (size_t)1, d_start, d_len, R, G, gc, per_win, (unsigned)cap);
+        else
+            hipLaunchKernelGGL(k_median2<false>, dim3((unsigned)(R * G), (unsigned)n_win), dim3(256), 0, st, data, flags,
+                               med, WS, WS, RS, (size_t)1, d_start, d_len, R, G, gc, per_win, (unsigned)cap);
+        hipError_t le = hipGetLastError();
+        hipError_t se = hipStreamSynchronize(st);
+        (void)hipFree(gc); (void)hipFree(d_start); (void)hipFree(d_len);
+        if (le != hipSuccess || se != hipSuccess) return set_err(TRI_EHIP, "median variant %d failed", variant);
+        return TRI_OK;
+    } else if (variant == 7) {
         if (row_len % 4 != 0) return set_err(TRI_EINVAL, "variant 7 needs row_len % 4 == 0");
         hipLaunchKernelGGL(k_median2<true>, dim3((unsigned)(R * G), (unsigned)n_win), dim3(256), 0, st, data, flags,
                            med, WS, WS, RS, (size_t)1, d_start, d_len, R, G);
