@@ -207,7 +207,7 @@ k_median(const float* __restrict__ data, const uint8_t* __restrict__ flags,
 // ---------------------------------------------------------------------------
 #define SEL2_CAND 4096
 #ifndef MED2_WIN
-#define MED2_WIN 24u                 // half-width (bins) of the candidate window around the predicted bin (K3c with prediction)
+#define MED2_WIN 8u                  // half-width (bins) of the candidate window around the predicted bin (K3c with prediction)
 #endif
 #ifndef MED2_UNROLL
 #define MED2_UNROLL 4          // 16-byte groups in flight per thread
@@ -481,7 +481,7 @@ k_median2(const float* __restrict__ data, const uint8_t* __restrict__ flags,
 
     // ---- pass 0b (callers with a candidate buffer): PREDICT the bin of the median from 64 runs of 256
     // consecutive samples (4 % of the segment, coalesced).  Pass 1 then also appends every key within
-    // MED2_WIN bins of the prediction to the candidate buffer in global memory (~7 % of the keys); when the
+    // MED2_WIN bins of the prediction to the candidate buffer in global memory (~2.5 % of the keys); when the
     // true bin -- known once the histogram is complete -- lies inside that window, the exact select runs on
     // the candidates and the segment has been read ONCE.  A miss costs the second pass it always used to.
     bool predict = gcand != nullptr && hi >= lo && len >= 65536 && ES == 1;
@@ -545,8 +545,20 @@ k_median2(const float* __restrict__ data, const uint8_t* __restrict__ flags,
         // the window holds the median: exact select of rank (n/2 - keys below the window) among its keys
         const unsigned nc = sh_ncand, excw = sh_excw, below1 = sh_below1;
         __syncthreads();   // sh[] is reused by select3 below
+        // (host: cand_ws and cand_cap are multiples of 4 -> 16-byte aligned list; eight groups in flight)
         auto enumerate_gc = [&](auto&& visit) {
-            for (unsigned i = tid; i < nc; i += 256) visit(gcand[i]);
+            const uint4* g4 = reinterpret_cast<const uint4*>(gcand);
+            const unsigned n4 = nc >> 2;
+            unsigned i = tid;
+            for (; i + 256 * 7 < n4; i += 256 * 8) {
+                uint4 q[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) q[u] = g4[i + 256 * u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { visit(q[u].x); visit(q[u].y); visit(q[u].z); visit(q[u].w); }
+            }
+            for (; i < n4; i += 256) { const uint4 q = g4[i]; visit(q.x); visit(q.y); visit(q.z); visit(q.w); }
+            if ((unsigned)tid < (nc & 3u)) visit(gcand[(n4 << 2) + tid]);
         };
         Sel3State st = select3(hist, sh, enumerate_gc, (long long)((total >> 1) - excw));
         st.n = total;

@@ -412,7 +412,7 @@ int launch_median(const Run& r, const float* data, const uint8_t* flags, double*
         else {
             // scratch for the predicted-window candidates (K3c): one read of the segment instead of two
             static const bool no_predict = [] { const char* e = getenv("TRI_MEDIAN_NO_PREDICT"); return e && e[0] == '1'; }();
-            if (no_predict || cand_cap < max_len) { gcand = nullptr; cand_ws = 0; cand_cap = 0; }
+            if (no_predict || cand_cap < max_len || cand_ws % 4 != 0 || cand_cap % 4 != 0 || ((uintptr_t)gcand % 16 != 0)) { gcand = nullptr; cand_ws = 0; cand_cap = 0; }
             if (vec_ok || row4)
                 hipLaunchKernelGGL(k_median2<true>, grid, dim3(256), 0, r.st, data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G, gcand, cand_ws, cand_cap);
             else
@@ -1131,7 +1131,7 @@ int background2d(const Run& r, bool flagsFT_current) {
             // (the time stage's images in ws.Aw / ws.Ao are dead here: candidate scratch, wsA / G keys per block)
             rc = launch_median(r, ws.Bo, ws.bgfFT, ws.med, wsB, N, 0, 1, ws.segB_start, ws.segB_len, 1, G, W, pl.maxchunk * pl.T,
                                T % 4 == 0 && wsB % 4 == 0 && N % 4 == 0, false, false,
-                               reinterpret_cast<unsigned*>(ws.Aw), wsA, (unsigned)std::min<size_t>(wsA / (size_t)G, 0x7fffffffu));
+                               reinterpret_cast<unsigned*>(ws.Aw), wsA, (unsigned)(std::min<size_t>(wsA / (size_t)G, 0x7fffffffu) & ~(size_t)3));
             if (rc) return rc;
             static const bool no_fuse = [] { const char* e = getenv("TRI_NO_FUSED_REJECT"); return e && e[0] == '1'; }();
             if (r.pl.vec && wsB % 4 == 0 && packed && !no_fuse) {
@@ -1823,7 +1823,7 @@ extern "C" int tri_test_median(const float* data, const uint8_t* flags, double* 
         // K3c with the predicted-window candidates in global scratch (9: vector loads, 10: scalar)
         if (variant == 9 && row_len % 4 != 0) return set_err(TRI_EINVAL, "variant 9 needs row_len % 4 == 0");
         unsigned* gc = nullptr;
-        const size_t cap = (size_t)maxlen, per_win = cap * (size_t)R * G;
+        const size_t cap = ((size_t)maxlen + 3) & ~(size_t)3, per_win = cap * (size_t)R * G;
         HIPCHK(hipMalloc(&gc, per_win * (size_t)n_win * sizeof(unsigned)));
         if (variant == 9)
             hipLaunchKernelGGL(k_median2<true>, dim3((unsigned)(R * G), (unsigned)n_win), dim3(256), 0, st, data, flags,
