@@ -15,12 +15,18 @@ call raises ``RuntimeError``.
 import ctypes as C
 import os
 import threading
+import time
 
 import numpy as np
 
 from tricolour_amd import _lib
 
 _tls = threading.local()
+# host-array calls take turns on the PCIe link (TRICOLOUR_AMD_LINK_TURNS=0: free-for-all)
+_H2D_TURN = threading.Lock()
+_D2H_TURN = _H2D_TURN
+_LINK_TURNS = os.environ.get("TRICOLOUR_AMD_LINK_TURNS", "1") != "0"
+_TRACE = [] if os.environ.get("TRICOLOUR_AMD_TRACE") == "1" else None   # (debug) per-call phase times
 
 
 def _torch():
@@ -151,6 +157,15 @@ def _host_call_stream(torch, vis, flags):
     return streams[key]
 
 
+def _d2h_stage(torch, nbytes):
+    """This thread's pinned staging buffer for results (grown on demand, reused by every later call)."""
+    st = getattr(_tls, "d2h_stage", None)
+    if st is None or st.numel() < nbytes:
+        _tls.d2h_stage = None
+        st = _tls.d2h_stage = torch.empty(int(nbytes), dtype=torch.uint8).pin_memory()
+    return st
+
+
 def _as_device_inputs(torch, vis, flags):
     """Returns (vis_tensor, flags_u8_tensor, vis_dtype_code, from_numpy, device)."""
     from_numpy = isinstance(vis, np.ndarray) or isinstance(flags, np.ndarray)
@@ -171,8 +186,22 @@ def _as_device_inputs(torch, vis, flags):
             return a.to(device)
         return torch.as_tensor(np.asarray(a)).to(device)
 
-    v = to_t(vis)
-    f = to_t(flags)
+    if from_numpy and _LINK_TURNS:
+        # One block on the link at a time.  A single copy already saturates it, so queueing the copies
+        # loses nothing -- but it staggers the calling threads: while one block's kernels run, the next
+        # thread's block is on the link, instead of all threads copying together and then computing
+        # together (measured: 2.2 -> see profiles/r02_host_path.txt).
+        t0 = time.time()
+        with _H2D_TURN:
+            t1 = time.time()
+            v = to_t(vis)
+            f = to_t(flags)
+            torch.cuda.current_stream(device).synchronize()
+        if _TRACE is not None:
+            _TRACE.append((threading.get_ident(), "h2d", t0, t1, time.time()))
+    else:
+        v = to_t(vis)
+        f = to_t(flags)
     if v.dtype == torch.complex64:
         code = _lib.TRI_VIS_C64
     elif v.dtype == torch.float32:
@@ -304,6 +333,26 @@ def _flag_on_current_stream(torch, lib, p, vis, flags, average_freq, _debug):
                 C.byref(p), None, 0, None))
     out = out.view(torch.bool)
     if from_numpy:
+        if _LINK_TURNS:
+            t0 = time.time()
+            torch.cuda.current_stream(device).synchronize()     # kernels done before queueing for the link
+            t1 = time.time()
+            # The result goes to a fresh numpy array, whose pages the kernel has to zero and map first:
+            # copied into directly, that happens page by page INSIDE the device-to-host copy (5-10 GB/s, and
+            # it drags down a concurrent host-to-device copy of another thread).  So: device -> this thread's
+            # pinned staging buffer at the link rate (5 ms for a 16-baseline block), link released, then a
+            # plain CPU copy into the fresh array.
+            stage = _d2h_stage(torch, out.numel())
+            with _D2H_TURN:
+                t2 = time.time()
+                stage[:out.numel()].copy_(out.view(torch.uint8).reshape(-1), non_blocking=True)
+                torch.cuda.current_stream(device).synchronize()
+            t3 = time.time()
+            res = np.empty((nbl, ncorr, ntime, nchan), np.bool_)
+            np.copyto(res.reshape(-1).view(np.uint8), stage[:out.numel()].numpy())
+            if _TRACE is not None:
+                _TRACE.append((threading.get_ident(), "kernels+d2h", t0, t1, t2, t3, time.time()))
+            return res
         return out.cpu().numpy()
     return out
 
