@@ -144,6 +144,46 @@ def test_interpolation_across_segments(gpu, oracle):
     _compare(gpu, oracle, vis, flags, kw, "segmented interpolation")
 
 
+def _time_stage(data, flags, radius, variant):
+    """tri_bench_boxfilter stage 0: data (W, n, C) float32, flags (W, n, C) bool -> filtered weight / data images."""
+    import ctypes as C
+    import torch
+    from tricolour_amd import _lib
+    w, n, c = data.shape
+    d = torch.from_numpy(np.ascontiguousarray(data, np.float32)).cuda()
+    # TF4 packing: byte k of word [t // 4][c] = flag of time 4 (t // 4) + k
+    f4 = np.ascontiguousarray(flags.astype(np.uint8).reshape(w, n // 4, 4, c).transpose(0, 1, 3, 2))
+    f = torch.from_numpy(f4).cuda()
+    ow = torch.full((w, n, c), -7.0, dtype=torch.float32, device="cuda")
+    oo = torch.full((w, n, c), -7.0, dtype=torch.float32, device="cuda")
+    ms = C.c_float(0)
+    _lib.check(_lib.lib().tri_bench_boxfilter(d.data_ptr(), f.data_ptr(), ow.data_ptr(), oo.data_ptr(), w, n, c, radius,
+                                              0, variant, 1, C.byref(ms), None))
+    torch.cuda.synchronize()
+    return ow.cpu().numpy(), oo.cpu().numpy()
+
+
+@pytest.mark.parametrize("shape,radius", [((2, 64, 70), 8), ((1, 256, 64), 10), ((2, 1024, 130), 21), ((1, 512, 64), 32),
+                                          ((2, 1024, 70), 43), ((1, 1024, 200), 54), ((1, 128, 64), 27), ((2, 64, 6), 15),
+                                          ((1, 16, 64), 54), ((1, 2048, 64), 12)])
+def test_time_stage_routes(gpu, shape, radius):
+    """Time-axis stage of the 2-D background filter: LDS delay lines (variant 1), register delay lines K4r (2), the
+    four-wave stage pipeline K4q (3) and the flagger's own route (0) agree bit for bit -- every (register part, FIFO
+    delay) split of the delay line, lines shorter than the filter, ragged column counts, NaN data under flags."""
+    rs = np.random.RandomState(radius * 100 + shape[1])
+    data = (rs.standard_normal(shape) * 3 + 10).astype(np.float32)
+    flags = rs.uniform(size=shape) < 0.1
+    flags[:, shape[1] // 3: shape[1] // 3 + 3 * radius, 0] = True       # a gap wider than the filter
+    data[flags & (rs.uniform(size=shape) < 0.3)] = np.nan
+    ref = _time_stage(data, flags, radius, 1)
+    for variant in (2, 3, 0):
+        got = _time_stage(data, flags, radius, variant)
+        for name, a, b in (("weights", ref[0], got[0]), ("data", ref[1], got[1])):
+            ok = _same_f32(a, b)
+            assert ok.all(), "variant %d, %s image: %d of %d words differ (first at %s)" % (
+                variant, name, (~ok).sum(), ok.size, np.argwhere(~ok)[0])
+
+
 def test_random_windows_multi_batch(gpu, oracle):
     """Several windows, tiny workspace budget -> several internal batches."""
     import os
@@ -746,7 +786,7 @@ print("DIFF", bad)
 @pytest.mark.parametrize("knob", ["TRI_NO_AMPL_CACHE", "TRI_FILTER_NO_FUSED_DIV", "TRI_FILTER_NO_TIN", "TRI_FILTER_NO_LANE4",
                                   "TRI_NO_PACKED_FLAGS", "TRI_FILTER_MULTIPASS", "TRI_ST_GENERIC", "TRI_ST_REGISTER",
                                   "TRI_FILTER_DIRECT_FT", "TRI_FILTER_NO_REGRING", "TRI_FILTER_NO_REGRING_F", "TRI_MEDIAN_3PASS",
-                                  "TRI_NO_FUSED_REJECT", "TRI_NO_FT_SPEC_OR", "TRI_NO_FUSED_BEGIN", "TRI_NO_FUSED_DILATE", "TRI_SPEC_NO_PIPE", "TRI_INTERP_ONE_PASS", "TRI_MEDIAN_NO_PREDICT"])
+                                  "TRI_NO_FUSED_REJECT", "TRI_NO_FT_SPEC_OR", "TRI_NO_FUSED_BEGIN", "TRI_NO_FUSED_DILATE", "TRI_SPEC_NO_PIPE", "TRI_INTERP_ONE_PASS", "TRI_MEDIAN_NO_PREDICT", "TRI_FILTER_NO_PIPE_T"])
 def test_alternate_kernel_paths(gpu, knob):
     """Every fallback / A-B path selectable through an environment knob (read once
     per process, hence the subprocess) stays bit-exact against the oracle."""

@@ -154,13 +154,16 @@ __device__ __forceinline__ void boxp_body(const float* __restrict__ srcData, con
                         o[u] = (V)acc;
                         acc -= (A)xold[u];
                     }
-                    if (!whole) {
-                        asm volatile("" ::: "memory");          // (a real branch: interior blocks skip the masks)
+                    if (whole) {                                // interior blocks: no masks (both arms store: a real branch)
 #pragma unroll
-                        for (int u = 0; u < B; u++) o[u] = (t0 + u >= keep_lo && t0 + u < keep_hi) ? o[u] : (V)0;
+                        for (int u = 0; u < B; u++) po2[u * 64] = o[u];
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < B; u++) {
+                            o[u] = (t0 + u >= keep_lo && t0 + u < keep_hi) ? o[u] : (V)0;
+                            po2[u * 64] = o[u];
+                        }
                     }
-#pragma unroll
-                    for (int u = 0; u < B; u++) po2[u * 64] = o[u];
                     if (pin == 0) {
 #pragma unroll
                         for (int u = 0; u < B; u++) po2[(Lc + u) * 64] = o[u];
@@ -202,4 +205,190 @@ k_boxp_spec(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFl
             float* __restrict__ dstW, float* __restrict__ dstO, int n, int C, int r, float denom) {
     if (blockIdx.y == 0) boxp_body<0, B, P>(srcData, srcFlags, dstW, n, C, r, denom);
     else boxp_body<1, B, P>(srcData, srcFlags, dstO, n, C, r, denom);
+}
+
+// ---------------------------------------------------------------------------
+// K4q  The stage pipeline for the 2-D time-axis stage, delay lines in REGISTERS.
+//
+// With one stage per wave a delay line is 2r values per lane -- it fits the register file where the
+// four delay lines of K4r (kernels_boxline.hpp) do not.  The newest KS = 16 * floor(2r / 16) positions of
+// delay are registers addressed statically (the iteration loop is unrolled over KS / 16 blocks;
+// "R[slot] = in" is a register rename, not a move); the remaining d = 2r - KS < 16 positions come for
+// free from the inter-stage FIFO: a stage reads its input block twice from LDS, once as it is (the sample
+// entering the sum) and once d positions back (the sample entering the register delay line), so what
+// leaves the registers entered 2r positions ago.  The FIFOs hold three blocks (+ a mirror of the first,
+// so that no 16-position read wraps); there is no LDS ring.
+// Per position and wave: 2 LDS reads, 5 arithmetic instructions, 1 LDS write, and two workgroups fit a
+// compute unit, so the barrier per block and the dependent float64 adds of one wave overlap with the
+// other workgroup's work.
+//
+// Same schedule as K4p: iteration j stages block j (data rows + TF4 flag words, fetched P blocks ahead),
+// wave s runs stage s + 1 over block j - s - 1, everybody stores block j - 5.  Thread (wave w, lane l)
+// stages / stores positions 4w .. 4w + 3 of column l: one flag word covers them.
+// grid (ceil(C / 64), W), block 256; host: n % 4 == 0, window below 2^31 bytes, 16 <= 2r, 2r - KS < 16.
+// ---------------------------------------------------------------------------
+#define BOXQ_LDS_BYTES ((4 * 4 * 16 * 64 + 2 * 16 * 64) * 4)   // 72 KB: two workgroups per compute unit
+__host__ __device__ constexpr int boxq_prefetch(int ks) { return ks == 48 || ks == 96 ? 6 : (ks == 80 ? 5 : 4); }
+__host__ __device__ constexpr int boxq_lcm(int a, int b) {
+    int x = a, y = b;
+    while (y) { int t = x % y; x = y; y = t; }
+    return a / x * b;
+}
+
+template <int IMG, int KS, int P>
+__device__ __forceinline__ void boxq_body(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags,
+                                          float* __restrict__ dst, const int n, const int C, const int r, const BoxDenom denom,
+                                          const size_t sws, const size_t dws, const size_t win) {
+    using V = typename std::conditional<IMG == 0, int, float>::type;
+    using A = typename std::conditional<IMG == 0, int, double>::type;
+    constexpr int B = 16;
+    constexpr int NBLK = KS / B;
+    constexpr int U = boxq_lcm(NBLK, P);
+    constexpr unsigned OOB = 0x7ffffff0u;
+    static_assert(KS % B == 0 && KS >= B, "register part: whole blocks");
+    extern __shared__ float cf_ring[];                         // dynamic LDS: BOXQ_LDS_BYTES
+    typedef V FifoT[4 * B][64];                                // one stage's input stream: 3 blocks + mirror of the first
+    typedef float OutT[B][64];
+    FifoT* fifo = reinterpret_cast<FifoT*>(cf_ring);           // [4]
+    OutT* outb = reinterpret_cast<OutT*>(cf_ring + 4 * 4 * B * 64);   // [2] output blocks of stage 4
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int R2 = 2 * r;
+    const int d = R2 - KS;                                     // host: 0 <= d < 16
+    const int c = blockIdx.x * 64 + lane;
+    const bool colok = c < C;
+    const int NB = (n + 4 * r + B - 1) / B;                    // every stage runs over t in [0, n + 4r)
+    const unsigned rowb = (unsigned)C * 4u;
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void*)(srcFlags + win * sws), 0, (int)((unsigned)(n / 4) * rowb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)(srcData + win * sws), 0, (int)((unsigned)n * rowb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)(dst + win * dws), 0, (int)((unsigned)n * rowb), 0x00020000);
+    const unsigned coff = (unsigned)c * 4u;
+    for (int k = tid; k < 4 * 4 * B * 64; k += 256) reinterpret_cast<V*>(cf_ring)[k] = 0;
+
+    unsigned pref[P];                                          // TF4 word: flags of positions 4w .. 4w + 3
+    float prex[IMG == 1 ? P : 1][4];
+    auto issue = [&](int blk, int q) {
+        const int t = blk * B + 4 * wave;                      // multiple of 4; n % 4 == 0: all four positions in or out
+        const bool ok = colok && t < n;
+        pref[q] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(frs, (int)(ok ? (unsigned)(t >> 2) * rowb + coff : OOB), 0, 0);
+        if (IMG == 1) {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                prex[q][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, (int)(ok ? (unsigned)(t + k) * rowb + coff : OOB), 0, 0));
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < P; q++) issue(q, q);
+
+    V R[KS];
+#pragma unroll
+    for (int k = 0; k < KS; k++) R[k] = 0;
+    A acc = 0;
+    int lslot = 0;                                             // FIFO block slot the staging writes next
+    int slot = 0, s0 = 3 * B - d;                              // this wave's input block slot / first row of the delayed window
+    if (s0 >= 3 * B) s0 -= 3 * B;
+    // a stage's output is masked where the NEXT stage does not take it (see boxline_step):
+    // stage 2 takes out_1[t] for t < n + 2r, stage 4 takes out_3[t] for t >= 2r
+    const int keep_lo = wave == 2 ? R2 : 0;
+    const int keep_hi = wave == 0 ? n + R2 : 0x7fffffff;
+    __syncthreads();
+
+    for (int j0 = 0; j0 < NB + 5; j0 += U) {
+#pragma unroll
+        for (int qq = 0; qq < U; qq++) {
+            const int j = j0 + qq;
+            const int q = qq % P;                              // prefetch slot (static)
+            const int sb = (qq % NBLK) * B;                    // register delay-line slots of this iteration (static)
+            {                                                  // stage block j into the stage-1 FIFO (LDS only)
+                const int t = j * B + 4 * wave;
+                const bool tin = colok && t < n;               // beyond the line end: flagged
+                V sv[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const bool fl = !tin || ((pref[q] >> (8 * k)) & 0xFFu) != 0;
+                    if (IMG == 0) sv[k] = fl ? (V)0 : (V)1;
+                    else sv[k] = fl ? (V)0 : (V)prex[IMG == 1 ? q : 0][k];
+                }
+                V* p = &fifo[0][lslot * B + 4 * wave][lane];
+#pragma unroll
+                for (int k = 0; k < 4; k++) p[k * 64] = sv[k];
+                if (lslot == 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) p[(3 * B + k) * 64] = sv[k];
+                }
+                lslot = lslot == 2 ? 0 : lslot + 1;
+            }
+            issue(j + P, q);                                   // fetch block j + P (always issued)
+            const int b = j - wave - 1;
+            if (b >= 0 && b < NB) {
+                const int t0 = b * B;
+                const V* pi = &fifo[wave][slot * B][lane];
+                const V* pd = &fifo[wave][s0][lane];
+                V xin[B], xdel[B], o[B];
+#pragma unroll
+                for (int u = 0; u < B; u++) { xin[u] = pi[u * 64]; xdel[u] = pd[u * 64]; }
+#pragma unroll
+                for (int u = 0; u < B; u++) {
+                    const V old = R[sb + u];                   // entered the registers KS positions ago, the sum 2r positions ago
+                    R[sb + u] = xdel[u];
+                    acc += (A)xin[u];
+                    o[u] = (V)acc;
+                    acc -= (A)old;
+                }
+                if (wave == 3) {
+                    float* ob = &outb[b & 1][0][lane];
+#pragma unroll
+                    for (int u = 0; u < B; u++) ob[u * 64] = (float)o[u];
+                } else {
+                    const bool whole = t0 >= keep_lo && t0 + B <= keep_hi;
+                    V* po = &fifo[wave + 1][slot * B][lane];
+                    if (whole) {                                // interior blocks: no masks (both arms store: a real branch)
+#pragma unroll
+                        for (int u = 0; u < B; u++) po[u * 64] = o[u];
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < B; u++) {
+                            o[u] = (t0 + u >= keep_lo && t0 + u < keep_hi) ? o[u] : (V)0;
+                            po[u * 64] = o[u];
+                        }
+                    }
+                    if (slot == 0) {
+#pragma unroll
+                        for (int u = 0; u < B; u++) po[(3 * B + u) * 64] = o[u];
+                    }
+                }
+                slot = slot == 2 ? 0 : slot + 1;
+                s0 = s0 + B >= 3 * B ? s0 + B - 3 * B : s0 + B;
+            }
+            {                                                  // store block j - 5 (always issued)
+                const int bs = j - 5;
+                const int i0 = bs * B + 4 * wave - 4 * r;
+                const float* ob = &outb[bs & 1][4 * wave][lane];
+                // division by the launch constant through its reciprocal (kernels_boxline.hpp: exact wherever the
+                // class test passes, checked for all 2^32 inputs per radius; anything else is redone by IEEE division)
+                float a[4], y[4];
+                unsigned long long okm = ~0ull;
+#pragma unroll
+                for (int k = 0; k < 4; k++) { a[k] = ob[k * 64]; y[k] = box_divide(a[k], denom, okm); }
+                if (okm != ~0ull) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) y[k] = box_divide_ieee(a[k], denom);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int i = i0 + k;
+                    const bool ok = bs >= 0 && bs < NB && i >= 0 && i < n && colok;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[k]), ors, (int)(ok ? (unsigned)i * rowb + coff : OOB), 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int KS, int IMG>
+__global__ void __launch_bounds__(256, 2)
+k_boxq(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags, float* __restrict__ dstImg,
+       int n, int C, int r, BoxDenom denom, size_t sws, size_t dws) {
+    boxq_body<IMG, KS, boxq_prefetch(KS)>(srcData, srcFlags, dstImg, n, C, r, denom, sws, dws, blockIdx.y);
 }

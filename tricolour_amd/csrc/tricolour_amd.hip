@@ -576,6 +576,49 @@ int launch_boxp_spec_b(const Run& r, const float* srcData, const uint8_t* srcFla
     return TRI_OK;
 }
 
+// K4q (kernels_boxpipe.hpp): register part of the delay lines for radius rad, 0 when it does not apply.
+// TRI_FILTER_NO_PIPE_T=1 keeps the K4r / LDS kernels.
+#ifndef BOXQ_MIN_2R
+#define BOXQ_MIN_2R 72
+#endif
+static thread_local int g_boxq_override = -1;   // tests / benches: 0 = off, 1 = on wherever it applies
+static int boxq_pick_ks(int rad) {
+    static const bool off = [] { const char* e = getenv("TRI_FILTER_NO_PIPE_T"); return e && e[0] == '1'; }();
+    if (g_boxq_override == 0 || (off && g_boxq_override < 0)) return 0;
+    const int ks = 2 * rad / 16 * 16;
+    return (ks >= 16 && ks <= 96) ? ks : 0;
+}
+
+template <int KS>
+int launch_boxq_ks(const Run& r, const float* srcData, const uint8_t* srcFlags, float* dstW, float* dstO,
+                   int n, int C, int rad, float denom, size_t sws, size_t dws, int64_t W) {
+    static const hipError_t attr = [] {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boxq<KS, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boxq<KS, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return e;
+    }();
+    HIPCHK(attr);
+    dim3 grid((unsigned)cdiv(C, 64), (unsigned)W);
+    const BoxDenom dn = box_reciprocal(denom);
+    hipLaunchKernelGGL((k_boxq<KS, 0>), grid, dim3(256), BOXQ_LDS_BYTES, r.st, srcData, srcFlags, dstW, n, C, rad, dn, sws, dws);
+    hipLaunchKernelGGL((k_boxq<KS, 1>), grid, dim3(256), BOXQ_LDS_BYTES, r.st, srcData, srcFlags, dstO, n, C, rad, dn, sws, dws);
+    LAUNCHCHK();
+    return TRI_OK;
+}
+
+int launch_boxq(const Run& r, int ks, const float* srcData, const uint8_t* srcFlags, float* dstW, float* dstO,
+                int n, int C, int rad, float denom, size_t sws, size_t dws, int64_t W) {
+    switch (ks) {
+        case 16: return launch_boxq_ks<16>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
+        case 32: return launch_boxq_ks<32>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
+        case 48: return launch_boxq_ks<48>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
+        case 64: return launch_boxq_ks<64>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
+        case 80: return launch_boxq_ks<80>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
+        case 96: return launch_boxq_ks<96>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
+    }
+    return set_err(TRI_EINVAL, "no stage-pipeline kernel for %d slots", ks);
+}
+
 int launch_boxt(const Run& r, int ks, const float* srcData, const uint8_t* srcFlags, float* dstW, float* dstO,
                 int n, int C, int rad, float denom, size_t sws, size_t dws, int64_t W) {
     switch (ks) {
@@ -605,6 +648,10 @@ int launch_colfilter(const Run& r, int srcmode, float* bufW, float* bufO, const 
     if (srcmode == 0 && !deferred_denom && !transposed_out && weights_are_01 && W == 1 && boxr_pick_ks(rad) > 0 &&
         (uint64_t)n * (uint64_t)C * 4u < (1ull << 31))
         return launch_boxt_spec(r, boxr_pick_ks(rad), srcData, srcFlags, dstW, dstO, n, C, rad, denom);
+    if (srcmode == 2 && !deferred_denom && !transposed_out && weights_are_01 && boxq_pick_ks(rad) > 0 && rad <= 107 &&
+        (g_boxq_override == 1 || 2 * rad >= BOXQ_MIN_2R) &&   // measured (1008 windows): K4r 13.4 / 19.1 / 23.0 / 23.7 ms at r = 21 / 32 / 43 / 54, K4q 19.1 / 20.0 / 20.4 / 20.5
+        n % 4 == 0 && (uint64_t)n * (uint64_t)C * 4u < (1ull << 31))
+        return launch_boxq(r, boxq_pick_ks(rad), srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
     if (srcmode == 2 && !deferred_denom && !transposed_out && weights_are_01 && boxr_pick_ks_t(rad) > 0 &&
         n % 4 == 0 && (uint64_t)n * (uint64_t)C * 4u < (1ull << 31))   // signed 32-bit buffer offsets
         return launch_boxt(r, boxr_pick_ks_t(rad), srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
@@ -1673,6 +1720,8 @@ extern "C" int tri_bench_boxfilter(const float* data, const uint8_t* flags4, flo
     g_boxr_override = variant == 0 ? -1 : (variant == 1 ? 0 : 1);
     // stage 2: 0 = the flagger's route, 1 = register rings, 2 / 3 = stage pipeline with blocks of 16 / 8
     if (stage == 2) { g_boxr_override = -1; g_boxp_override = variant == 0 ? -1 : (variant == 1 ? 0 : (variant == 2 ? 16 : 8)); }
+    // stage 0: 0 = the flagger's route, 1 = LDS delay lines, 2 = register delay lines (K4r), 3 = stage pipeline (K4q)
+    if (stage == 0) { g_boxq_override = variant == 0 ? -1 : (variant == 3 ? 1 : 0); if (variant == 3) g_boxr_override = -1; }
     int rc = TRI_OK;
     HIPCHK(hipEventRecord(e0, r.st));
     for (int i = 0; i < repeats && rc == TRI_OK; i++) {
@@ -1706,6 +1755,7 @@ extern "C" int tri_bench_boxfilter(const float* data, const uint8_t* flags4, flo
     }
     g_boxr_override = -1;
     g_boxp_override = -1;
+    g_boxq_override = -1;
     if (rc) return rc;
     HIPCHK(hipEventRecord(e1, r.st));
     HIPCHK(hipEventSynchronize(e1));
