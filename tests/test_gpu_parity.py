@@ -184,6 +184,45 @@ def test_time_stage_routes(gpu, shape, radius):
                 variant, name, (~ok).sum(), ok.size, np.argwhere(~ok)[0])
 
 
+def _freq_stage(wimg, oimg, data, radius, variant):
+    """tri_bench_boxfilter stage 1: time-filtered weight / data images (W, T, F), amplitudes (W, F, T) ->
+    |data - background| (W, F, T)."""
+    import ctypes as C
+    import torch
+    from tricolour_amd import _lib
+    w, t, f = wimg.shape
+    both = torch.from_numpy(np.ascontiguousarray(np.stack([wimg, oimg], axis=1), np.float32)).cuda()
+    d = torch.from_numpy(np.ascontiguousarray(data, np.float32)).cuda()
+    ow = torch.full((w, f, t), -7.0, dtype=torch.float32, device="cuda")
+    oo = torch.full((w, f, t), -7.0, dtype=torch.float32, device="cuda")
+    ms = C.c_float(0)
+    _lib.check(_lib.lib().tri_bench_boxfilter(d.data_ptr(), both.data_ptr(), ow.data_ptr(), oo.data_ptr(), w, t, f, radius,
+                                              1, variant, 1, C.byref(ms), None))
+    torch.cuda.synchronize()
+    return oo.cpu().numpy()
+
+
+@pytest.mark.parametrize("shape,radius", [((2, 64, 128), 8), ((1, 72, 256), 10), ((2, 132, 1024), 21), ((1, 64, 512), 32),
+                                          ((2, 36, 1024), 43), ((1, 200, 1024), 54), ((1, 64, 128), 27), ((1, 8, 64), 17),
+                                          ((1, 64, 16), 54)])
+def test_frequency_stage_routes(gpu, shape, radius):
+    """Frequency-axis stage fused with the masked division: LDS delay lines (variant 1), register delay lines
+    K4r (2), the eight-wave stage pipeline K4qf (3) and the flagger's own route (0) agree bit for bit, including
+    zero-weight bands (NaN background), lines shorter than the filter and ragged line counts."""
+    w, t, f = shape
+    rs = np.random.RandomState(radius * 100 + f)
+    wimg = (rs.uniform(size=shape) * 0.9 + 0.05).astype(np.float32)
+    wimg[:, :, f // 3: f // 3 + 5 * radius] = 0.0               # fully flagged band wider than the filter -> NaN background
+    wimg[:, 1, :] = 0.0                                          # a line without any weight
+    oimg = (wimg * (rs.standard_normal(shape) * 3 + 10)).astype(np.float32)
+    data = (rs.standard_normal((w, f, t)) * 3 + 10).astype(np.float32)
+    ref = _freq_stage(wimg, oimg, data, radius, 1)
+    for variant in (2, 3, 0):
+        got = _freq_stage(wimg, oimg, data, radius, variant)
+        ok = _same_f32(ref, got)
+        assert ok.all(), "variant %d: %d of %d words differ (first at %s)" % (variant, (~ok).sum(), ok.size, np.argwhere(~ok)[0])
+
+
 def test_random_windows_multi_batch(gpu, oracle):
     """Several windows, tiny workspace budget -> several internal batches."""
     import os
@@ -786,7 +825,7 @@ print("DIFF", bad)
 @pytest.mark.parametrize("knob", ["TRI_NO_AMPL_CACHE", "TRI_FILTER_NO_FUSED_DIV", "TRI_FILTER_NO_TIN", "TRI_FILTER_NO_LANE4",
                                   "TRI_NO_PACKED_FLAGS", "TRI_FILTER_MULTIPASS", "TRI_ST_GENERIC", "TRI_ST_REGISTER",
                                   "TRI_FILTER_DIRECT_FT", "TRI_FILTER_NO_REGRING", "TRI_FILTER_NO_REGRING_F", "TRI_MEDIAN_3PASS",
-                                  "TRI_NO_FUSED_REJECT", "TRI_NO_FT_SPEC_OR", "TRI_NO_FUSED_BEGIN", "TRI_NO_FUSED_DILATE", "TRI_SPEC_NO_PIPE", "TRI_INTERP_ONE_PASS", "TRI_MEDIAN_NO_PREDICT", "TRI_FILTER_NO_PIPE_T"])
+                                  "TRI_NO_FUSED_REJECT", "TRI_NO_FT_SPEC_OR", "TRI_NO_FUSED_BEGIN", "TRI_NO_FUSED_DILATE", "TRI_SPEC_NO_PIPE", "TRI_INTERP_ONE_PASS", "TRI_MEDIAN_NO_PREDICT", "TRI_FILTER_NO_PIPE_T", "TRI_FILTER_NO_PIPE_F"])
 def test_alternate_kernel_paths(gpu, knob):
     """Every fallback / A-B path selectable through an environment knob (read once
     per process, hence the subprocess) stays bit-exact against the oracle."""

@@ -392,3 +392,186 @@ k_boxq(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags, 
        int n, int C, int r, BoxDenom denom, size_t sws, size_t dws) {
     boxq_body<IMG, KS, boxq_prefetch(KS)>(srcData, srcFlags, dstImg, n, C, r, denom, sws, dws, blockIdx.y);
 }
+
+// ---------------------------------------------------------------------------
+// K4qf  The same pipeline for the frequency-axis stage, fused with the masked division (what k_boxf
+// does with register + LDS rings at one wave per SIMD).  One workgroup of EIGHT waves filters both
+// images of 64 lines: waves 0-3 are the four stages of the weight image, waves 4-7 those of the
+// weight * data image; every block of 16 positions both fourth stages leave their sums in LDS and all
+// 512 threads finish two (position, line) pairs each:
+//     w = W / d^4, o = O / d^4, bg = (w == 0) ? NaN : o / w        (flagging.py:419, 506-513)
+//     MODE 1: dstO = |data - bg|                                    (rejection loop, :563-566)
+//     MODE 2: dstO = bg, dstW = data - bg, nanflag[line] = 1 on a NaN   (:576-578, :962)
+// Input images stored transposed (the time-axis stage's TF output: line c is row c of a [C][ld] array,
+// the data image img_gap elements after the weight image): a block is 64 row segments of 16 floats per
+// image, one float4 per thread, transposed on its way into the stage-1 FIFO.  Outputs and `data` are
+// position-major [n][C] (coalesced along the lines).  The filtered images are never written.
+// grid (ceil(C / 64), W), block 512, dynamic LDS BOXQF_LDS_BYTES (one workgroup = two waves per SIMD).
+// Host: n % 4 == 0, ld % 4 == 0, img_gap % 4 == 0, 16-byte aligned images, windows below 2^31 bytes.
+// ---------------------------------------------------------------------------
+#define BOXQF_LDS_BYTES ((2 * 4 * 4 * 16 * 64 + 2 * 2 * 16 * 64) * 4)   // 144 KB
+template <int KS, int MODE>
+__global__ void __launch_bounds__(512, 1)
+k_boxqf(const float* __restrict__ srcW, unsigned img_gap, float* __restrict__ dstW, float* __restrict__ dstO,
+        const float* __restrict__ data, int n, int C, int ld, int r, BoxDenom denom, size_t sws_img, size_t dws,
+        size_t ws_data, uint8_t* __restrict__ nanflag) {
+    constexpr int B = 16;
+    constexpr int P = boxq_prefetch(KS);
+    constexpr int NBLK = KS / B;
+    constexpr int U = boxq_lcm(NBLK, P);
+    constexpr unsigned OOB = 0x7ffffff0u;
+    extern __shared__ float cf_ring[];
+    typedef float FifoT[4 * B][64];                            // one stage's input stream: 3 blocks + mirror of the first
+    typedef float OutT[B][64];
+    FifoT* fifo = reinterpret_cast<FifoT*>(cf_ring);           // [2 images][4 stages]
+    OutT* outb = reinterpret_cast<OutT*>(cf_ring + 2 * 4 * 4 * B * 64);   // [2 images][2 blocks]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int img = wave >> 2, st = wave & 3;                  // this wave's image and stage
+    const size_t win = blockIdx.y;
+    const int c0 = blockIdx.x * 64;
+    const int R2 = 2 * r;
+    const int d = R2 - KS;                                     // host: 0 <= d < 16
+    const int NB = (n + 4 * r + B - 1) / B;
+    for (int k = tid; k < 2 * 4 * 4 * B * 64; k += 512) cf_ring[k] = 0.0f;
+
+    // staging: thread -> image (tid >> 8), line (tid & 255) / 4, positions 4 (tid & 3) .. + 3 of a block
+    const int s_line = (tid & 255) >> 2, s_q = tid & 3;
+    const bool s_lok = c0 + s_line < C;
+    const float* s_base = srcW + win * sws_img + (size_t)(img ? img_gap : 0u) + (size_t)(s_lok ? c0 + s_line : 0) * ld;
+    float pre[P][4];
+    auto issue = [&](int blk, int q) {
+        const int p = blk * B + 4 * s_q;                       // n % 4 == 0: the four positions are in or out together
+        const float4 v = *reinterpret_cast<const float4*>(s_base + (p < n ? p : 0));
+        pre[q][0] = v.x; pre[q][1] = v.y; pre[q][2] = v.z; pre[q][3] = v.w;
+    };
+    // finishing: thread -> line tid & 63, positions (tid >> 6) and (tid >> 6) + 8 of a block
+    const int f_u = tid >> 6;
+    const int c = c0 + lane;
+    const bool colok = c < C;
+    const unsigned rowb = (unsigned)C * 4u;
+    const unsigned coff = (unsigned)c * 4u;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(data + win * ws_data), 0, (int)((unsigned)n * rowb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)(dstO + win * dws), 0, (int)((unsigned)n * rowb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)(dstW + win * dws), 0, (int)((unsigned)n * rowb), 0x00020000);
+    float dpre[P][2];
+    auto issue_data = [&](int blk, int q) {                    // data samples of output block blk
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int i = blk * B + f_u + 8 * h - 4 * r;
+            const bool ok = blk >= 0 && i >= 0 && i < n && colok;
+            dpre[q][h] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)(ok ? (unsigned)i * rowb + coff : OOB), 0, 0));
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < P; q++) { issue(q, q); issue_data(q - 5, q); }
+
+    float R[KS];
+#pragma unroll
+    for (int k = 0; k < KS; k++) R[k] = 0.0f;
+    double acc = 0.0;
+    int lslot = 0;
+    int slot = 0, s0 = 3 * B - d;
+    if (s0 >= 3 * B) s0 -= 3 * B;
+    const int keep_lo = st == 2 ? R2 : 0;
+    const int keep_hi = st == 0 ? n + R2 : 0x7fffffff;
+    bool line_nan = false;
+    __syncthreads();
+
+    for (int j0 = 0; j0 < NB + 5; j0 += U) {
+#pragma unroll
+        for (int qq = 0; qq < U; qq++) {
+            const int j = j0 + qq;
+            const int q = qq % P;
+            const int sb = (qq % NBLK) * B;
+            {                                                  // stage block j (transposed) into this image's stage-1 FIFO
+                const int p = j * B + 4 * s_q;
+                const bool ok = s_lok && p < n;                // beyond the line end / the last line: zero input
+                float* pf = &fifo[img * 4][lslot * B + 4 * s_q][s_line];
+#pragma unroll
+                for (int k = 0; k < 4; k++) pf[k * 64] = ok ? pre[q][k] : 0.0f;
+                if (lslot == 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) pf[(3 * B + k) * 64] = ok ? pre[q][k] : 0.0f;
+                }
+                lslot = lslot == 2 ? 0 : lslot + 1;
+            }
+            issue(j + P, q);                                   // (always issued: clamped address)
+            const int b = j - st - 1;
+            if (b >= 0 && b < NB) {
+                const int t0 = b * B;
+                const float* pi = &fifo[wave][slot * B][lane];
+                const float* pd = &fifo[wave][s0][lane];
+                float xin[B], xdel[B], o[B];
+#pragma unroll
+                for (int u = 0; u < B; u++) { xin[u] = pi[u * 64]; xdel[u] = pd[u * 64]; }
+#pragma unroll
+                for (int u = 0; u < B; u++) {
+                    const float old = R[sb + u];
+                    R[sb + u] = xdel[u];
+                    acc += (double)xin[u];
+                    o[u] = (float)acc;
+                    acc -= (double)old;
+                }
+                if (st == 3) {
+                    float* ob = &outb[img * 2 + (b & 1)][0][lane];
+#pragma unroll
+                    for (int u = 0; u < B; u++) ob[u * 64] = o[u];
+                } else {
+                    const bool whole = t0 >= keep_lo && t0 + B <= keep_hi;
+                    float* po = &fifo[wave + 1][slot * B][lane];
+                    if (whole) {
+#pragma unroll
+                        for (int u = 0; u < B; u++) po[u * 64] = o[u];
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < B; u++) {
+                            o[u] = (t0 + u >= keep_lo && t0 + u < keep_hi) ? o[u] : 0.0f;
+                            po[u * 64] = o[u];
+                        }
+                    }
+                    if (slot == 0) {
+#pragma unroll
+                        for (int u = 0; u < B; u++) po[(3 * B + u) * 64] = o[u];
+                    }
+                }
+                slot = slot == 2 ? 0 : slot + 1;
+                s0 = s0 + B >= 3 * B ? s0 + B - 3 * B : s0 + B;
+            }
+            {                                                  // finish block j - 5 (stores always issued)
+                const int bs = j - 5;
+                float wq[2], oq[2], a0[2], a1[2];
+                unsigned long long okm = ~0ull;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    a0[h] = outb[bs & 1][f_u + 8 * h][lane];
+                    a1[h] = outb[2 + (bs & 1)][f_u + 8 * h][lane];
+                    wq[h] = box_divide(a0[h], denom, okm);     // deferred flagging.py:419
+                    oq[h] = box_divide(a1[h], denom, okm);
+                }
+                if (okm != ~0ull) {
+#pragma unroll
+                    for (int h = 0; h < 2; h++) { wq[h] = box_divide_ieee(a0[h], denom); oq[h] = box_divide_ieee(a1[h], denom); }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int i = bs * B + f_u + 8 * h - 4 * r;
+                    const bool ok = bs >= 0 && bs < NB && i >= 0 && i < n && colok;
+                    const unsigned off = ok ? (unsigned)i * rowb + coff : OOB;
+                    const float bg = (wq[h] == 0.0f) ? NAN : oq[h] / wq[h];
+                    const float dv = dpre[q][h];
+                    if (MODE == 1) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fabsf(dv - bg)), ors, (int)off, 0, 0);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bg), ors, (int)off, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dv - bg), wrs, (int)off, 0, 0);
+                        line_nan |= ok && isnan(bg);
+                    }
+                }
+            }
+            issue_data(j + P - 5, q);                          // data samples of the block finished P iterations from now
+            __syncthreads();
+        }
+    }
+    if (MODE == 2 && line_nan) nanflag[win * (size_t)C + c] = 1;
+}

@@ -581,7 +581,7 @@ int launch_boxp_spec_b(const Run& r, const float* srcData, const uint8_t* srcFla
 #ifndef BOXQ_MIN_2R
 #define BOXQ_MIN_2R 72
 #endif
-static thread_local int g_boxq_override = -1;   // tests / benches: 0 = off, 1 = on wherever it applies
+thread_local int g_boxq_override = -1;   // tests / benches: 0 = off, 1 = on wherever it applies
 static int boxq_pick_ks(int rad) {
     static const bool off = [] { const char* e = getenv("TRI_FILTER_NO_PIPE_T"); return e && e[0] == '1'; }();
     if (g_boxq_override == 0 || (off && g_boxq_override < 0)) return 0;
@@ -940,9 +940,47 @@ int launch_boxf_ks(const Run& r, const float* srcW, const float* srcO, float* ds
     return TRI_OK;
 }
 
+static int boxq_pick_ks(int rad);
+extern thread_local int g_boxq_override;
+// K4qf: the fused frequency stage as an eight-wave stage pipeline (kernels_boxpipe.hpp)
+#ifndef BOXQF_MIN_2R
+#define BOXQF_MIN_2R 34
+#endif
+template <int KS, int MODE>
+int launch_boxqf_ks(const Run& r, const float* srcW, unsigned gap, float* dstW, float* dstO, const float* data,
+                    int n, int C, int ld, int rad, size_t sws_img, size_t dws, size_t ws_data, int64_t W, uint8_t* nanflag) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boxqf<KS, MODE>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    HIPCHK(attr);
+    const BoxDenom denom = box_reciprocal(box_denominator(rad));
+    dim3 grid((unsigned)cdiv(C, 64), (unsigned)W);
+    hipLaunchKernelGGL((k_boxqf<KS, MODE>), grid, dim3(512), BOXQF_LDS_BYTES, r.st, srcW, gap, dstW, dstO, data, n, C, ld, rad,
+                       denom, sws_img, dws, ws_data, nanflag);
+    LAUNCHCHK();
+    return TRI_OK;
+}
+
 template <int MODE>
 int launch_boxf(const Run& r, int ks, const float* srcW, const float* srcO, float* dstW, float* dstO, const float* data,
                 int n, int C, int ld, int rad, size_t sws_img, size_t dws, size_t ws_data, int64_t W, uint8_t* nanflag) {
+    {
+        static const bool off = [] { const char* e = getenv("TRI_FILTER_NO_PIPE_F"); return e && e[0] == '1'; }();
+        const int kq = boxq_pick_ks(rad);
+        const bool want = g_boxq_override == 1 || (g_boxq_override < 0 && !off && 2 * rad >= BOXQF_MIN_2R);
+        if (want && kq > 0 && srcO > srcW && n % 4 == 0 && ld % 4 == 0 && sws_img % 4 == 0 && (uint64_t)(srcO - srcW) % 4 == 0 &&
+            ((uintptr_t)srcW % 16 == 0) && ((uint64_t)(srcO - srcW) + (uint64_t)C * ld) * 4u < (1ull << 31) &&
+            (uint64_t)n * (uint64_t)C * 4u < (1ull << 31)) {
+            const unsigned gap = (unsigned)(srcO - srcW);
+            switch (kq) {
+                case 16: return launch_boxqf_ks<16, MODE>(r, srcW, gap, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
+                case 32: return launch_boxqf_ks<32, MODE>(r, srcW, gap, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
+                case 48: return launch_boxqf_ks<48, MODE>(r, srcW, gap, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
+                case 64: return launch_boxqf_ks<64, MODE>(r, srcW, gap, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
+                case 80: return launch_boxqf_ks<80, MODE>(r, srcW, gap, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
+                case 96: return launch_boxqf_ks<96, MODE>(r, srcW, gap, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
+            }
+        }
+    }
     switch (ks) {
         case 8: return launch_boxf_ks<8, MODE>(r, srcW, srcO, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
         case 16: return launch_boxf_ks<16, MODE>(r, srcW, srcO, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
@@ -1721,7 +1759,7 @@ extern "C" int tri_bench_boxfilter(const float* data, const uint8_t* flags4, flo
     // stage 2: 0 = the flagger's route, 1 = register rings, 2 / 3 = stage pipeline with blocks of 16 / 8
     if (stage == 2) { g_boxr_override = -1; g_boxp_override = variant == 0 ? -1 : (variant == 1 ? 0 : (variant == 2 ? 16 : 8)); }
     // stage 0: 0 = the flagger's route, 1 = LDS delay lines, 2 = register delay lines (K4r), 3 = stage pipeline (K4q)
-    if (stage == 0) { g_boxq_override = variant == 0 ? -1 : (variant == 3 ? 1 : 0); if (variant == 3) g_boxr_override = -1; }
+    if (stage == 0 || stage == 1) { g_boxq_override = variant == 0 ? -1 : (variant == 3 ? 1 : 0); if (variant == 3) g_boxr_override = -1; }
     int rc = TRI_OK;
     HIPCHK(hipEventRecord(e0, r.st));
     for (int i = 0; i < repeats && rc == TRI_OK; i++) {
