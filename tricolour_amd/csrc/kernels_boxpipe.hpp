@@ -471,8 +471,11 @@ k_boxqf(const float* __restrict__ srcW, unsigned img_gap, float* __restrict__ ds
     for (int k = 0; k < KS; k++) R[k] = 0.0f;
     double acc = 0.0;
     int lslot = 0;
-    int slot = 0, s0 = 3 * B - d;
-    if (s0 >= 3 * B) s0 -= 3 * B;
+    // Every wave runs its stage in EVERY iteration, also over the st + 1 blocks before its first one (all-zero
+    // input: sums and delay line stay zero) and past its last (results never stored): no branch around the
+    // arithmetic, so it can be scheduled together with the finishing work.  Block j - st - 1 sits in FIFO slot
+    // (j - st - 1) mod 3; the delayed window starts d rows earlier.
+    int slot = (3 * 8 - st - 1) % 3, s0 = (3 * B * 8 - (st + 1) * B - d) % (3 * B);
     const int keep_lo = st == 2 ? R2 : 0;
     const int keep_hi = st == 0 ? n + R2 : 0x7fffffff;
     bool line_nan = false;
@@ -498,7 +501,7 @@ k_boxqf(const float* __restrict__ srcW, unsigned img_gap, float* __restrict__ ds
             }
             issue(j + P, q);                                   // (always issued: clamped address)
             const int b = j - st - 1;
-            if (b >= 0 && b < NB) {
+            {
                 const int t0 = b * B;
                 const float* pi = &fifo[wave][slot * B][lane];
                 const float* pd = &fifo[wave][s0][lane];
@@ -518,7 +521,7 @@ k_boxqf(const float* __restrict__ srcW, unsigned img_gap, float* __restrict__ ds
 #pragma unroll
                     for (int u = 0; u < B; u++) ob[u * 64] = o[u];
                 } else {
-                    const bool whole = t0 >= keep_lo && t0 + B <= keep_hi;
+                    const bool whole = t0 >= keep_lo && t0 + B <= keep_hi && b >= 0;
                     float* po = &fifo[wave + 1][slot * B][lane];
                     if (whole) {
 #pragma unroll
