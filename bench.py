@@ -217,10 +217,10 @@ def roofline_boxfilter(torch, device, T, F, kw, nwin):
     stream = torch.cuda.current_stream(device).cuda_stream
     nit = int(kw.get("background_iterations", 1))
     swt, swf = float(kw.get("spike_width_time", 12.5)), float(kw.get("spike_width_freq", 10.0))
-    cases = [(0, box_radius(max(nit, 1) * swt), "time-axis stage (k_boxt / k_colfilter_lds), first background iteration"),
+    cases = [(0, box_radius(max(nit, 1) * swt), "time-axis stage (k_boxq / k_boxt / k_colfilter_lds), first background iteration"),
              (1, box_radius(swf), "frequency-axis stage fused with the masked division (k_boxf), last background pass")]
     if nit > 1:
-        cases.insert(1, (1, box_radius(nit * swf), "frequency-axis stage fused with the masked division (k_boxf), first background iteration"))
+        cases.insert(1, (1, box_radius(nit * swf), "frequency-axis stage fused with the masked division (k_boxqf), first background iteration"))
     samples = nwin * T * F
     out = []
     for stage, rad, what in cases:

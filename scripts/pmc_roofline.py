@@ -58,9 +58,13 @@ for e in roof:
         emit("sumthreshold", e, ["k_colst_mask"], "dword-per-lane row loads (x2 on FETCH_SIZE, calibrated in round 1 on this kernel's known byte count), byte stores")
     elif "time-axis" in k:
         rad = int(k.rsplit("r = ", 1)[1])
-        pats = ["k_boxt"] if rad >= 16 else ["k_colfilter_lds<2"]
+        pats = ["k_boxq<"] if 72 <= 2 * rad < 112 else (["k_boxt"] if rad >= 16 else ["k_colfilter_lds<2"])
         emit("boxfilter_s0_r%d" % rad, e, pats, "one launch per image (weight: packed flag words in, float32 out; data: + float32 in); dword-per-lane accesses")
     elif "frequency-axis" in k:
         rad = int(k.rsplit("r = ", 1)[1])
-        ks = 80 if 2 * rad >= 80 else 64 if 2 * rad >= 64 else 32 if 2 * rad >= 32 else 16 if 2 * rad >= 16 else 8
-        emit("boxfilter_s1_r%d" % rad, e, ["k_boxf<%d, %s, 1," % (ks, "true" if 2 * rad > ks else "false")], "both images + amplitudes in, |data - background| out; 64-byte row segments in, dword-per-lane out")
+        if 34 <= 2 * rad < 112:
+            pat = "k_boxqf<%d, 1>" % (2 * rad // 16 * 16)
+        else:
+            ks = 80 if 2 * rad >= 80 else 64 if 2 * rad >= 64 else 32 if 2 * rad >= 32 else 16 if 2 * rad >= 16 else 8
+            pat = "k_boxf<%d, %s, 1," % (ks, "true" if 2 * rad > ks else "false")
+        emit("boxfilter_s1_r%d" % rad, e, [pat], "both images + amplitudes in, |data - background| out; 64-byte row segments in, dword-per-lane out")
