@@ -248,7 +248,9 @@ int tri_version(void);
  * `variant`: 0 = best available for these windows, 1 = generic (dynamic
  * windows, global rings), 2 = register cascade (windows 1,2,4,8 only),
  * 3 = lane-mask cascade (windows 1,2,4,8, window below 2^31 bytes; what 0
- * selects for those).
+ * selects for those), 4 = stage pipeline across the waves of a workgroup with
+ * the prefix rings in LDS (K7p; any list of up to eight windows whose rings
+ * fit 160 KB, e.g. 32, 48, 64, 128 -- the flagger's route for such lists).
  */
 int tri_bench_sumthreshold(const float *data, const double *mad, uint8_t *out,
                            int64_t n_win, int64_t n_line, int64_t n_col,

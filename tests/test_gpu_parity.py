@@ -349,6 +349,34 @@ def test_fused_sumthreshold_kernel_vs_generic_and_oracle(gpu, oracle, shape):
         assert np.array_equal(mask, gen), "lane-mask cascade"
 
 
+@pytest.mark.parametrize("shape,windows", [((2, 700, 70), (32, 48, 64, 128)), ((1, 300, 64), (32, 48, 64, 128)),
+                                           ((1, 100, 130), (32, 48, 64, 128)), ((2, 200, 64), (1, 2, 4, 8)),
+                                           ((1, 500, 200), (3, 5, 16, 17, 40)), ((1, 64, 64), (1, 2, 4, 8, 16, 32, 64, 128)),
+                                           ((1, 2000, 64), (7,))])
+def test_sumthreshold_stage_pipeline_vs_generic_and_oracle(gpu, oracle, shape, windows):
+    """K7p (one window per wave, prefix rings in LDS) against the generic global-scratch kernel and the oracle:
+    final_st_very_broad's windows, lists of one to eight windows, windows wider than the line, lines of many
+    blocks, NaN MADs, ragged column counts."""
+    rs = np.random.RandomState(shape[1] + len(windows))
+    data = rs.standard_normal(shape).astype(np.float32) * 2.0
+    data[:, shape[1] // 3: shape[1] // 3 + 40, :] += 3.0      # broad bump: only the wide windows see it
+    data[:, :, 5] -= 25.0
+    data[0, -1, :] += 40.0
+    data[0, 0, :3] -= 40.0
+    flags = rs.uniform(size=shape) < 0.1
+    flags[:, :, 7] = True
+    mad = np.empty((shape[0], shape[2]), np.float64)
+    for w in range(shape[0]):
+        mad[w] = oracle.median_abs_axis0(data[w], flags[w]).astype(np.float64).reshape(-1)
+    wl = [w for w in windows if w <= shape[1]]
+    gen = _run_st_kernel(data, mad, wl, 4.5, 1.3, 1)
+    pipe = _run_st_kernel(data, mad, wl, 4.5, 1.3, 4)
+    assert np.array_equal(pipe, gen), "%d flags differ" % (pipe != gen).sum()
+    for w in range(shape[0]):
+        exp = oracle.sum_threshold(data[w], flags[w], 0, np.array(wl), 4.5, 1.3)
+        assert np.array_equal(pipe[w], exp), "window %d" % w
+
+
 @pytest.mark.parametrize("n_line", [16, 40, 100])
 def test_sumthreshold_hit_only_in_last_window_position(gpu, oracle, n_line):
     """A sample that only the widest window STARTING at it can flag (seven
@@ -825,7 +853,7 @@ print("DIFF", bad)
 @pytest.mark.parametrize("knob", ["TRI_NO_AMPL_CACHE", "TRI_FILTER_NO_FUSED_DIV", "TRI_FILTER_NO_TIN", "TRI_FILTER_NO_LANE4",
                                   "TRI_NO_PACKED_FLAGS", "TRI_FILTER_MULTIPASS", "TRI_ST_GENERIC", "TRI_ST_REGISTER",
                                   "TRI_FILTER_DIRECT_FT", "TRI_FILTER_NO_REGRING", "TRI_FILTER_NO_REGRING_F", "TRI_MEDIAN_3PASS",
-                                  "TRI_NO_FUSED_REJECT", "TRI_NO_FT_SPEC_OR", "TRI_NO_FUSED_BEGIN", "TRI_NO_FUSED_DILATE", "TRI_SPEC_NO_PIPE", "TRI_INTERP_ONE_PASS", "TRI_MEDIAN_NO_PREDICT", "TRI_FILTER_NO_PIPE_T", "TRI_FILTER_NO_PIPE_F"])
+                                  "TRI_NO_FUSED_REJECT", "TRI_NO_FT_SPEC_OR", "TRI_NO_FUSED_BEGIN", "TRI_NO_FUSED_DILATE", "TRI_SPEC_NO_PIPE", "TRI_INTERP_ONE_PASS", "TRI_MEDIAN_NO_PREDICT", "TRI_FILTER_NO_PIPE_T", "TRI_FILTER_NO_PIPE_F", "TRI_ST_NO_PIPE"])
 def test_alternate_kernel_paths(gpu, knob):
     """Every fallback / A-B path selectable through an environment knob (read once
     per process, hence the subprocess) stays bit-exact against the oracle."""

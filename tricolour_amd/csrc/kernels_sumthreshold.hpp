@@ -116,6 +116,225 @@ k_colst_dyn(const float* __restrict__ data, const double* __restrict__ med,
 }
 
 // ---------------------------------------------------------------------------
+// K7p  The dynamic cascade as a STAGE PIPELINE across the waves of a workgroup (any window list of up to
+// eight windows whose rings fit LDS: final_st_very_broad's 32, 48, 64, 128).
+// k_colst_dyn keeps every thread's prefix rings in global memory -- 2176 bytes per thread for those four
+// windows, 1.1 GB across the resident threads, re-read every w positions: the kernel is bound by that HBM
+// traffic (0.11 TB/s of algorithmic bytes).  Here a workgroup of nw waves owns 64 lines (lane = column):
+// wave j runs ONLY window j, its ring of w_j float64 prefix values per lane lives in LDS ([slot][lane]),
+// and the per-position (pos, neg) bits travel from stage to stage through a circular LDS byte buffer.
+// Positions are processed in blocks of 16 with one workgroup barrier per block; stage j + 1 runs
+// ceil((w_j - 1) / 16) + 1 blocks behind stage j, i.e. behind every position stage j may still flag,
+// so its clamp sees exactly the flags of the stages before it -- as in K7 / flagging.py:638-674.  Every
+// float64 value is produced by the same operations in the same order as k_colst_dyn (and the reference).
+// grid (ceil(C / 64), G, W), block 64 * nw, dynamic LDS stp_lds_bytes(sw)
+// ---------------------------------------------------------------------------
+#define STP_B 16
+struct StPipe { int lag[TRI_MAX_WINDOWS + 1]; int accn; int ringoff_b[TRI_MAX_WINDOWS]; };
+__host__ inline StPipe stp_plan(const StWin& sw) {
+    StPipe pp{};
+    int lag = 0, off = 0;
+    for (int j = 0; j < sw.nw; j++) {
+        pp.lag[j] = lag;
+        pp.ringoff_b[j] = off;
+        lag += (sw.w[j] - 1 + STP_B - 1) / STP_B + 1;
+        off += sw.w[j] * 64 * 8;
+    }
+    pp.lag[sw.nw] = lag;
+    pp.accn = (lag + 2) * STP_B;
+    return pp;
+}
+__host__ inline size_t stp_lds_bytes(const StWin& sw) {
+    const StPipe pp = stp_plan(sw);
+    return (size_t)sw.ringtot * 64 * 8 + (size_t)pp.accn * 64;
+}
+
+__global__ void __launch_bounds__(512)
+k_colst_pipe(const float* __restrict__ data, const double* __restrict__ med, uint8_t* __restrict__ out,
+             const int64_t* __restrict__ chunk_ends, StWin sw, StPipe pp, double thr_scale, int L, int C, int G,
+             size_t ws_data, size_t ws_out) {
+    extern __shared__ double stp_lds[];
+    const int lane = threadIdx.x & 63;
+    const int j = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // this wave's window
+    const int nw = sw.nw;
+    const int g = blockIdx.y;
+    const size_t win = blockIdx.z;
+    const int c0 = (int)chunk_ends[g], c1 = (int)chunk_ends[g + 1];
+    if (c1 <= c0) return;                                      // (uniform: before any barrier)
+    const int c = blockIdx.x * 64 + lane;
+    const bool colok = c < C;
+    const int cc = colok ? c : C - 1;
+    // flagging.py:630-633 (slicing clamps to the axis length)
+    const int p0 = max(c0 - sw.maxw + 1, 0);
+    const int p1 = min(c1 + sw.maxw - 1, L);
+    const int Lp = p1 - p0;
+    const int w = sw.w[j];
+    double* ring = reinterpret_cast<double*>(reinterpret_cast<char*>(stp_lds) + pp.ringoff_b[j]) + lane;   // [slot][64]
+    uint8_t* acc = reinterpret_cast<uint8_t*>(stp_lds) + (size_t)sw.ringtot * 64 * 8 + lane;             // [position % accn][64]
+    const int accn = pp.accn;
+    for (int s = threadIdx.x; s < accn * 64; s += blockDim.x) (acc - lane)[s] = 0;
+    ring[0] = 0.0;                                             // cum[0] = 0 in slot 0
+    // flagging.py:622-628
+    const float mad = (float)med[(win * (size_t)C + cc) * G + g];
+    const float thr0 = isnan(mad) ? INFINITY : (float)((double)mad * thr_scale);
+    const double limit = (double)thr0 / sw.tf[j];
+    const double scale = sw.scale[j];
+    const float* x = data + win * ws_data + cc;
+    uint8_t* o = out + win * ws_out + c;
+    const size_t Cs = (size_t)C;
+    double cumlast = 0.0;
+    int sincep = 1 << 30, sincen = 1 << 30;
+    int slot = 1 % w;                                          // ring slot of prefix i + 1 (next to write / oldest to read)
+    int apos = 0;                                              // acc index of ingest position i
+    int aemit = (accn - (w - 1) % accn) % accn;                // acc index of emit position e = i + 1 - w
+    const int lag = pp.lag[j], lagF = pp.lag[nw];
+    const int NBs = (Lp + sw.maxw + STP_B - 1) / STP_B;        // blocks until every stage has emitted every position
+    const int NIT = NBs + lagF + 1;
+    float xn[STP_B];
+    auto fetch = [&](int b) {
+        if (b >= 0 && b * STP_B + STP_B <= Lp) {               // whole block inside the line: no per-element test
+            const float* xb = x + (size_t)(p0 + b * STP_B) * Cs;
+#pragma unroll
+            for (int u = 0; u < STP_B; u++) xn[u] = xb[(size_t)u * Cs];
+        } else {
+#pragma unroll
+            for (int u = 0; u < STP_B; u++) {
+                const int i = b * STP_B + u;
+                xn[u] = (b >= 0 && i < Lp) ? x[(size_t)(p0 + i) * Cs] : 0.0f;
+            }
+        }
+    };
+    // One block of 16 steps with every LDS read first and every LDS write last (windows of at least a block:
+    // nothing the block reads was written in it -- the prefix read at step u was written w >= 16 steps ago, a
+    // stage never sees its own flags).  ING / EMIT: every step of the block ingests / emits (uniform per block),
+    // so the 16 steps are straight-line code.
+    auto run_block = [&](const float (&xc)[STP_B], auto ing_tag, auto emit_tag) {
+        constexpr bool ING = decltype(ing_tag)::value, EMIT = decltype(emit_tag)::value;
+        uint8_t ain[STP_B], aem[STP_B];
+        double rold[STP_B], cumv[STP_B];
+        int sl[STP_B], em[STP_B];
+#pragma unroll
+        for (int u = 0; u < STP_B; u++) {
+            sl[u] = slot; em[u] = aemit;
+            if (ING) ain[u] = acc[(size_t)(apos + u) * 64];    // (accn is a multiple of 16: no wrap inside the block)
+            if (ING && EMIT) rold[u] = ring[(size_t)slot * 64];
+            if (EMIT) aem[u] = acc[(size_t)aemit * 64];
+            slot = slot + 1 == w ? 0 : slot + 1;
+            aemit = aemit + 1 == accn ? 0 : aemit + 1;
+        }
+        apos = apos + STP_B == accn ? 0 : apos + STP_B;
+#pragma unroll
+        for (int u = 0; u < STP_B; u++) {
+            bool hp = false, hn = false;
+            if (ING) {
+                const uint8_t a = ain[u];
+                double clamped = (double)xc[u];
+                const bool cp = (a & 1) && clamped > limit;
+                const bool cn = !cp && (a & 2) && clamped < -limit;
+                clamped = cp ? limit : (cn ? -limit : clamped);
+                const double cumnew = cumlast + clamped;
+                cumlast = cumnew;
+                cumv[u] = cumnew;
+                if (EMIT) {
+                    const double S = cumnew - rold[u];
+                    hp = S * scale > limit;
+                    hn = S * (-scale) > limit;
+                }
+            }
+            if (EMIT) {
+                // (counters start at 2^30 and a line has far fewer than 2^30 positions: no saturation needed here)
+                sincep = hp ? 0 : sincep + 1;
+                sincen = hn ? 0 : sincen + 1;
+                aem[u] |= (uint8_t)((sincep < w ? 1 : 0) | (sincen < w ? 2 : 0));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < STP_B; u++) {
+            if (ING) ring[(size_t)sl[u] * 64] = cumv[u];
+            if (EMIT) acc[(size_t)em[u] * 64] = aem[u];
+        }
+    };
+    fetch(-lag);                                               // (this wave's block 0 comes `lag` iterations in)
+    __syncthreads();
+    for (int it = 0; it < NIT; it++) {
+        const int b = it - lag;                                // this stage's block
+        float xc[STP_B];
+#pragma unroll
+        for (int u = 0; u < STP_B; u++) xc[u] = xn[u];
+        fetch(b + 1);
+        const int i0 = b * STP_B, e0 = i0 + 1 - w;             // first ingest / emit position of the block
+        const bool all_in = i0 + STP_B <= Lp, none_in = i0 >= Lp;
+        const bool all_em = e0 >= 0 && e0 + STP_B <= Lp, none_em = e0 + STP_B <= 0;
+        if (b >= 0 && b < NBs && w >= STP_B && all_in && all_em) {
+            run_block(xc, std::true_type{}, std::true_type{});
+        } else if (b >= 0 && b < NBs && w >= STP_B && all_in && none_em) {
+            run_block(xc, std::true_type{}, std::false_type{});
+        } else if (b >= 0 && b < NBs && w >= STP_B && none_in && all_em) {
+            run_block(xc, std::false_type{}, std::true_type{});
+        } else if (b >= 0 && b < NBs) {
+#pragma unroll
+            for (int u = 0; u < STP_B; u++) {
+                const int i = b * STP_B + u;                   // ingest position
+                const int e = i + 1 - w;                       // emit position
+                if (e < Lp) {
+                    bool hp = false, hn = false;
+                    if (i < Lp) {
+                        const uint8_t a = acc[(size_t)apos * 64];
+                        double clamped = (double)xc[u];
+                        if ((a & 1) && clamped > limit) clamped = limit;
+                        else if ((a & 2) && clamped < -limit) clamped = -limit;
+                        const double cumnew = cumlast + clamped;
+                        cumlast = cumnew;
+                        if (e >= 0) {
+                            const double S = cumnew - ring[(size_t)slot * 64];
+                            hp = S * scale > limit;
+                            hn = S * (-scale) > limit;
+                        }
+                        ring[(size_t)slot * 64] = cumnew;
+                    }
+                    if (e >= 0) {
+                        sincep = hp ? 0 : min(sincep + 1, 1 << 30);
+                        sincen = hn ? 0 : min(sincen + 1, 1 << 30);
+                        const uint8_t add = (sincep < w ? 1 : 0) | (sincen < w ? 2 : 0);
+                        if (add) acc[(size_t)aemit * 64] |= add;
+                    }
+                }
+                slot = slot + 1 == w ? 0 : slot + 1;
+                apos = apos + 1 == accn ? 0 : apos + 1;
+                aemit = aemit + 1 == accn ? 0 : aemit + 1;
+            }
+        }
+        // positions final after the last stage: written out (and their slots recycled) by wave 0
+        const int bf = it - lagF;
+        if (j == 0 && bf >= 0) {
+            const int f0 = bf * STP_B;
+            if (f0 + STP_B <= Lp && p0 + f0 >= c0 && p0 + f0 + STP_B <= c1) {   // whole block inside the chunk
+                const int as0 = f0 % accn;                     // (block-aligned: no wrap)
+#pragma unroll
+                for (int u = 0; u < STP_B; u++) {
+                    const uint8_t a = acc[(size_t)(as0 + u) * 64];
+                    acc[(size_t)(as0 + u) * 64] = 0;
+                    if (colok) o[(size_t)(p0 + f0 + u) * Cs] = a ? 1 : 0;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < STP_B; u++) {
+                    const int ef = f0 + u;
+                    if (ef < Lp) {
+                        const int as = ef % accn;
+                        const uint8_t a = acc[(size_t)as * 64];
+                        acc[(size_t)as * 64] = 0;
+                        const int pos = p0 + ef;
+                        if (pos >= c0 && pos < c1 && colok) o[(size_t)pos * Cs] = a ? 1 : 0;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K7b  Register-resident SumThreshold cascade for power-of-two windows
 // {W0,W1,W2,W3} with W3 <= 8 (the library default and every shipped strategy's
 // time axis: 1,2,4,8).  Same arithmetic as k_colst_dyn, but

@@ -753,6 +753,13 @@ int launch_colfilter(const Run& r, int srcmode, float* bufW, float* bufO, const 
     return TRI_OK;
 }
 
+// K7p applies: up to eight windows whose float64 prefix rings (+ the flag ring) fit the CU's LDS
+// (TRI_ST_NO_PIPE=1 keeps the global-scratch kernel)
+bool st_use_pipe(const StWin& sw) {
+    static const bool off = [] { const char* e = getenv("TRI_ST_NO_PIPE"); return e && e[0] == '1'; }();
+    return !off && sw.nw >= 1 && sw.nw <= 8 && stp_lds_bytes(sw) <= 160 * 1024;
+}
+
 int launch_colst(const Run& r, const StWin& sw, const float* data, const double* med,
                  uint8_t* out, const int64_t* d_chunk_ends, int L, int C, int G, size_t ws_data,
                  size_t ws_out, int64_t W) {
@@ -769,6 +776,14 @@ int launch_colst(const Run& r, const StWin& sw, const float* data, const double*
         else
             hipLaunchKernelGGL((k_colst_fused<1, 2, 4, 8>), grid, dim3(blk), 0, r.st, data, med, out,
                                d_chunk_ends, fa, thr_scale, L, C, G, ws_data, ws_out);
+    } else if (st_use_pipe(sw)) {
+        // any window list whose prefix rings fit LDS: one window per wave (K7p)
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colst_pipe),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        HIPCHK(attr);
+        dim3 gridp((unsigned)cdiv(C, 64), (unsigned)G, (unsigned)W);
+        hipLaunchKernelGGL(k_colst_pipe, gridp, dim3(64 * sw.nw), stp_lds_bytes(sw), r.st, data, med, out, d_chunk_ends, sw,
+                           stp_plan(sw), thr_scale, L, C, G, ws_data, ws_out);
     } else {
         hipLaunchKernelGGL(k_colst_dyn, grid, dim3(blk), 0, r.st, data, med, out, r.ws.ring, r.ws.acc,
                            d_chunk_ends, sw, thr_scale, L, C, G, ws_data, ws_out);
@@ -1710,6 +1725,10 @@ extern "C" int tri_bench_sumthreshold(const float* data, const double* mad, uint
     if (variant == 3 && !((uint64_t)L * (uint64_t)C * 4u < (1ull << 31)))
         return set_err(TRI_EUNSUPPORTED, "lane-mask cascade needs a window below 2^31 bytes");
     if (variant == 0 && can_fuse) variant = st_use_mask(L, C) ? 3 : 2;
+    if (variant == 4) {
+        if (sw.nw > 8 || stp_lds_bytes(sw) > 160 * 1024) return set_err(TRI_EUNSUPPORTED, "stage pipeline: the prefix rings do not fit LDS");
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colst_pipe), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
     bool fused = variant == 2;
     StFusedArgs fa;
     for (int j = 0; j < 4; j++) fa.tf[j] = sw.tf[j < sw.nw ? j : 0];
@@ -1719,6 +1738,9 @@ extern "C" int tri_bench_sumthreshold(const float* data, const double* mad, uint
             hipLaunchKernelGGL((k_colst_mask<1, 2, 4, 8>), grid, dim3(blk), 0, st, data, mad, out, d_ends, fa, thr_scale, L, C, 1, ws, ws);
         else if (fused)
             hipLaunchKernelGGL((k_colst_fused<1, 2, 4, 8>), grid, dim3(blk), 0, st, data, mad, out, d_ends, fa, thr_scale, L, C, 1, ws, ws);
+        else if (variant == 4)
+            hipLaunchKernelGGL(k_colst_pipe, dim3((unsigned)cdiv(C, 64), 1, (unsigned)n_win), dim3(64 * sw.nw), stp_lds_bytes(sw), st,
+                               data, mad, out, d_ends, sw, stp_plan(sw), thr_scale, L, C, 1, ws, ws);
         else
             hipLaunchKernelGGL(k_colst_dyn, grid, dim3(blk), 0, st, data, mad, out, ring, acc, d_ends, sw, thr_scale, L, C, 1, ws, ws);
     }
