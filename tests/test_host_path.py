@@ -80,3 +80,32 @@ def test_wide_input_types(gpu, oracle):
     z.real[:, :, ::2] = amp[:, :, ::2]
     z.imag[:, :, 1::2] = -amp[:, :, 1::2].astype(np.float64)
     assert np.array_equal(gpu.sum_threshold_flagger(z, flags, **kw), expa)
+
+
+def test_numpy_result_paths_agree(gpu, oracle, monkeypatch):
+    """numpy in / numpy out: the result through the pinned staging buffer (default), straight into the fresh
+    array (results above the staging limit, or pinning unavailable) and with the link turns switched off are
+    the same flags -- from several threads at once."""
+    from concurrent.futures import ThreadPoolExecutor
+    from tricolour_amd import flagging
+    rs = np.random.RandomState(3)
+    shape = (4, 2, 48, 96)
+    vis = (rs.standard_normal(shape) + 1j * rs.standard_normal(shape)).astype(np.complex64)
+    vis[..., 40] *= 7
+    flags = rs.uniform(size=shape) < 0.04
+    exp = oracle.sum_threshold_flagger(vis, flags, num_major_iterations=2)
+
+    def run(_):
+        out = gpu.sum_threshold_flagger(vis, flags, num_major_iterations=2)
+        assert isinstance(out, np.ndarray) and out.dtype == np.bool_ and out.flags["C_CONTIGUOUS"] and out.flags["WRITEABLE"]
+        return out
+
+    with ThreadPoolExecutor(3) as pool:
+        outs = list(pool.map(run, range(6)))
+    assert all(np.array_equal(o, exp) for o in outs)
+    monkeypatch.setattr(flagging, "_D2H_STAGE_MAX", 0)             # staging refused: direct copy
+    assert np.array_equal(run(0), exp)
+    monkeypatch.setattr(flagging, "_LINK_TURNS", False)            # the earlier free-for-all path
+    with ThreadPoolExecutor(3) as pool:
+        outs = list(pool.map(run, range(3)))
+    assert all(np.array_equal(o, exp) for o in outs)

@@ -157,12 +157,21 @@ def _host_call_stream(torch, vis, flags):
     return streams[key]
 
 
+_D2H_STAGE_MAX = 1 << 30      # larger results (blocks of > 64 baselines of 1024 x 4096) go straight to their array
+
+
 def _d2h_stage(torch, nbytes):
-    """This thread's pinned staging buffer for results (grown on demand, reused by every later call)."""
+    """This thread's pinned staging buffer for results (grown on demand, reused by every later call);
+    None when the result is too large to keep pinned memory of its size around, or pinning fails."""
+    if nbytes > _D2H_STAGE_MAX:
+        return None
     st = getattr(_tls, "d2h_stage", None)
     if st is None or st.numel() < nbytes:
         _tls.d2h_stage = None
-        st = _tls.d2h_stage = torch.empty(int(nbytes), dtype=torch.uint8).pin_memory()
+        try:
+            st = _tls.d2h_stage = torch.empty(int(nbytes), dtype=torch.uint8).pin_memory()
+        except RuntimeError:
+            return None
     return st
 
 
@@ -343,6 +352,9 @@ def _flag_on_current_stream(torch, lib, p, vis, flags, average_freq, _debug):
             # pinned staging buffer at the link rate (5 ms for a 16-baseline block), link released, then a
             # plain CPU copy into the fresh array.
             stage = _d2h_stage(torch, out.numel())
+            if stage is None:
+                with _D2H_TURN:
+                    return out.cpu().numpy()
             with _D2H_TURN:
                 t2 = time.time()
                 stage[:out.numel()].copy_(out.view(torch.uint8).reshape(-1), non_blocking=True)
