@@ -229,6 +229,9 @@ k_boxp_spec(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFl
 // ---------------------------------------------------------------------------
 #define BOXQ_LDS_BYTES ((4 * 4 * 16 * 64 + 2 * 16 * 64) * 4)   // 72 KB: two workgroups per compute unit
 __host__ __device__ constexpr int boxq_prefetch(int ks) { return ks == 48 || ks == 96 ? 6 : (ks == 80 ? 5 : 4); }
+#ifndef BOXQ_ABLATE
+#define BOXQ_ABLATE 0                    // timing-only builds: 1 = no finishing, 2 = no stage arithmetic, 4 = no staging / loads
+#endif
 __host__ __device__ constexpr int boxq_lcm(int a, int b) {
     int x = a, y = b;
     while (y) { int t = x % y; x = y; y = t; }
@@ -299,6 +302,7 @@ __device__ __forceinline__ void boxq_body(const float* __restrict__ srcData, con
             const int j = j0 + qq;
             const int q = qq % P;                              // prefetch slot (static)
             const int sb = (qq % NBLK) * B;                    // register delay-line slots of this iteration (static)
+#if !(BOXQ_ABLATE & 4)
             {                                                  // stage block j into the stage-1 FIFO (LDS only)
                 const int t = j * B + 4 * wave;
                 const bool tin = colok && t < n;               // beyond the line end: flagged
@@ -319,7 +323,9 @@ __device__ __forceinline__ void boxq_body(const float* __restrict__ srcData, con
                 lslot = lslot == 2 ? 0 : lslot + 1;
             }
             issue(j + P, q);                                   // fetch block j + P (always issued)
+#endif
             const int b = j - wave - 1;
+#if !(BOXQ_ABLATE & 2)
             if (b >= 0 && b < NB) {
                 const int t0 = b * B;
                 const V* pi = &fifo[wave][slot * B][lane];
@@ -360,6 +366,8 @@ __device__ __forceinline__ void boxq_body(const float* __restrict__ srcData, con
                 slot = slot == 2 ? 0 : slot + 1;
                 s0 = s0 + B >= 3 * B ? s0 + B - 3 * B : s0 + B;
             }
+#endif
+#if !(BOXQ_ABLATE & 1)
             {                                                  // store block j - 5 (always issued)
                 const int bs = j - 5;
                 const int i0 = bs * B + 4 * wave - 4 * r;
@@ -381,6 +389,7 @@ __device__ __forceinline__ void boxq_body(const float* __restrict__ srcData, con
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[k]), ors, (int)(ok ? (unsigned)i * rowb + coff : OOB), 0, 0);
                 }
             }
+#endif
             __syncthreads();
         }
     }
