@@ -977,14 +977,18 @@ k_median_wave(const float* __restrict__ data, const uint8_t* __restrict__ flags,
         }
         prefix = wave_max_u32(cand);
     }
+    // the lower middle element (largest key below the selected one, or the selected one itself when it is
+    // duplicated below its rank) only enters an EVEN count's median (uniform per wave)
     unsigned cnt = 0, mx = 0;
+    if (!(n & 1u)) {
 #pragma unroll
-    for (int u = 0; u < KS; u++) {
-        unsigned k = keys[u];
-        if (k != SENT && k < prefix) { cnt++; mx = max(mx, k); }
+        for (int u = 0; u < KS; u++) {
+            unsigned k = keys[u];
+            if (k != SENT && k < prefix) { cnt++; mx = max(mx, k); }
+        }
+        cnt = wave_sum_u32(cnt);
+        mx = wave_max_u32(mx) + kmin;
     }
-    cnt = wave_sum_u32(cnt);
-    mx = wave_max_u32(mx) + kmin;
     const unsigned hi = prefix + kmin;
     if (live && lane == 0) {
         size_t oidx = (win * (size_t)R + row) * G + g;
