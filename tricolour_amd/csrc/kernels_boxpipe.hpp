@@ -418,15 +418,22 @@ k_boxq(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags, 
 // grid (ceil(C / 64), W), block 512, dynamic LDS BOXQF_LDS_BYTES (one workgroup = two waves per SIMD).
 // Host: n % 4 == 0, ld % 4 == 0, img_gap % 4 == 0, 16-byte aligned images, windows below 2^31 bytes.
 // ---------------------------------------------------------------------------
-#define BOXQF_LDS_BYTES ((2 * 4 * 4 * 16 * 64 + 2 * 2 * 16 * 64) * 4)   // 144 KB
-template <int KS, int MODE>
-__global__ void __launch_bounds__(512, 1)
+// LDS bytes for blocks of B positions: 144 KB at B = 16 (one workgroup per CU), 72 KB at B = 8 (two)
+__host__ __device__ constexpr size_t boxqf_lds_bytes(int B) { return (size_t)(2 * 4 * 4 * B * 64 + 2 * 2 * B * 64) * 4; }
+#define BOXQF_LDS_BYTES boxqf_lds_bytes(16)
+// B = 8: half the FIFO memory and, for delay lines of up to 48 registers, half the register budget: TWO workgroups
+// (four waves per SIMD) share a compute unit -- twice the barriers per position against twice the latency hiding.
+template <int KS, int MODE, int B = 16>
+__global__ void __launch_bounds__(512, B == 8 ? 2 : 1)
 k_boxqf(const float* __restrict__ srcW, unsigned img_gap, float* __restrict__ dstW, float* __restrict__ dstO,
         const float* __restrict__ data, int n, int C, int ld, int r, BoxDenom denom, size_t sws_img, size_t dws,
         size_t ws_data, uint8_t* __restrict__ nanflag) {
-    constexpr int B = 16;
-    constexpr int P = boxq_prefetch(KS);
+    constexpr int PP = B / 4;                                  // positions per thread when staging (4 or 2)
+    constexpr int FN = B / 8;                                  // (position, line) pairs per thread when finishing (2 or 1)
     constexpr int NBLK = KS / B;
+    constexpr int P = B == 8 ? (NBLK == 6 ? 3 : NBLK) : boxq_prefetch(KS);   // (B = 8: KS = 32, 40, 48 -> 4, 5, 3 blocks ahead: 128 registers)
+    static_assert(KS % B == 0, "register part: whole blocks");
+    static_assert(B == 8 || B == 16, "block length");
     constexpr int U = boxq_lcm(NBLK, P);
     constexpr unsigned OOB = 0x7ffffff0u;
     extern __shared__ float cf_ring[];
@@ -444,17 +451,22 @@ k_boxqf(const float* __restrict__ srcW, unsigned img_gap, float* __restrict__ ds
     const int NB = (n + 4 * r + B - 1) / B;
     for (int k = tid; k < 2 * 4 * 4 * B * 64; k += 512) cf_ring[k] = 0.0f;
 
-    // staging: thread -> image (tid >> 8), line (tid & 255) / 4, positions 4 (tid & 3) .. + 3 of a block
+    // staging: thread -> image (tid >> 8), line (tid & 255) / 4, positions PP (tid & 3) .. + PP - 1 of a block
     const int s_line = (tid & 255) >> 2, s_q = tid & 3;
     const bool s_lok = c0 + s_line < C;
     const float* s_base = srcW + win * sws_img + (size_t)(img ? img_gap : 0u) + (size_t)(s_lok ? c0 + s_line : 0) * ld;
-    float pre[P][4];
+    float pre[P][PP];
     auto issue = [&](int blk, int q) {
-        const int p = blk * B + 4 * s_q;                       // n % 4 == 0: the four positions are in or out together
-        const float4 v = *reinterpret_cast<const float4*>(s_base + (p < n ? p : 0));
-        pre[q][0] = v.x; pre[q][1] = v.y; pre[q][2] = v.z; pre[q][3] = v.w;
+        const int p = blk * B + PP * s_q;                      // n % 4 == 0: the positions are in or out together
+        if (PP == 4) {
+            const float4 v = *reinterpret_cast<const float4*>(s_base + (p < n ? p : 0));
+            pre[q][0] = v.x; pre[q][1] = v.y; pre[q][PP - 2] = v.z; pre[q][PP - 1] = v.w;
+        } else {
+            const float2 v = *reinterpret_cast<const float2*>(s_base + (p < n ? p : 0));
+            pre[q][0] = v.x; pre[q][1] = v.y;
+        }
     };
-    // finishing: thread -> line tid & 63, positions (tid >> 6) and (tid >> 6) + 8 of a block
+    // finishing: thread -> line tid & 63, position tid >> 6 (and that + 8 with blocks of 16)
     const int f_u = tid >> 6;
     const int c = c0 + lane;
     const bool colok = c < C;
@@ -463,10 +475,10 @@ k_boxqf(const float* __restrict__ srcW, unsigned img_gap, float* __restrict__ ds
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(data + win * ws_data), 0, (int)((unsigned)n * rowb), 0x00020000);
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)(dstO + win * dws), 0, (int)((unsigned)n * rowb), 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)(dstW + win * dws), 0, (int)((unsigned)n * rowb), 0x00020000);
-    float dpre[P][2];
+    float dpre[P][FN];
     auto issue_data = [&](int blk, int q) {                    // data samples of output block blk
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
+        for (int h = 0; h < FN; h++) {
             const int i = blk * B + f_u + 8 * h - 4 * r;
             const bool ok = blk >= 0 && i >= 0 && i < n && colok;
             dpre[q][h] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)(ok ? (unsigned)i * rowb + coff : OOB), 0, 0));
@@ -497,14 +509,14 @@ k_boxqf(const float* __restrict__ srcW, unsigned img_gap, float* __restrict__ ds
             const int q = qq % P;
             const int sb = (qq % NBLK) * B;
             {                                                  // stage block j (transposed) into this image's stage-1 FIFO
-                const int p = j * B + 4 * s_q;
+                const int p = j * B + PP * s_q;
                 const bool ok = s_lok && p < n;                // beyond the line end / the last line: zero input
-                float* pf = &fifo[img * 4][lslot * B + 4 * s_q][s_line];
+                float* pf = &fifo[img * 4][lslot * B + PP * s_q][s_line];
 #pragma unroll
-                for (int k = 0; k < 4; k++) pf[k * 64] = ok ? pre[q][k] : 0.0f;
+                for (int k = 0; k < PP; k++) pf[k * 64] = ok ? pre[q][k] : 0.0f;
                 if (lslot == 0) {
 #pragma unroll
-                    for (int k = 0; k < 4; k++) pf[(3 * B + k) * 64] = ok ? pre[q][k] : 0.0f;
+                    for (int k = 0; k < PP; k++) pf[(3 * B + k) * 64] = ok ? pre[q][k] : 0.0f;
                 }
                 lslot = lslot == 2 ? 0 : lslot + 1;
             }
@@ -552,10 +564,10 @@ k_boxqf(const float* __restrict__ srcW, unsigned img_gap, float* __restrict__ ds
             }
             {                                                  // finish block j - 5 (stores always issued)
                 const int bs = j - 5;
-                float wq[2], oq[2], a0[2], a1[2];
+                float wq[FN], oq[FN], a0[FN], a1[FN];
                 unsigned long long okm = ~0ull;
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
+                for (int h = 0; h < FN; h++) {
                     a0[h] = outb[bs & 1][f_u + 8 * h][lane];
                     a1[h] = outb[2 + (bs & 1)][f_u + 8 * h][lane];
                     wq[h] = box_divide(a0[h], denom, okm);     // deferred flagging.py:419
@@ -563,10 +575,10 @@ k_boxqf(const float* __restrict__ srcW, unsigned img_gap, float* __restrict__ ds
                 }
                 if (okm != ~0ull) {
 #pragma unroll
-                    for (int h = 0; h < 2; h++) { wq[h] = box_divide_ieee(a0[h], denom); oq[h] = box_divide_ieee(a1[h], denom); }
+                    for (int h = 0; h < FN; h++) { wq[h] = box_divide_ieee(a0[h], denom); oq[h] = box_divide_ieee(a1[h], denom); }
                 }
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
+                for (int h = 0; h < FN; h++) {
                     const int i = bs * B + f_u + 8 * h - 4 * r;
                     const bool ok = bs >= 0 && bs < NB && i >= 0 && i < n && colok;
                     const unsigned off = ok ? (unsigned)i * rowb + coff : OOB;

@@ -961,15 +961,18 @@ extern thread_local int g_boxq_override;
 #ifndef BOXQF_MIN_2R
 #define BOXQF_MIN_2R 34
 #endif
-template <int KS, int MODE>
+#ifndef BOXQF_B8_DEFAULT
+#define BOXQF_B8_DEFAULT 1
+#endif
+template <int KS, int MODE, int B = 16>
 int launch_boxqf_ks(const Run& r, const float* srcW, unsigned gap, float* dstW, float* dstO, const float* data,
                     int n, int C, int ld, int rad, size_t sws_img, size_t dws, size_t ws_data, int64_t W, uint8_t* nanflag) {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boxqf<KS, MODE>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boxqf<KS, MODE, B>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     HIPCHK(attr);
     const BoxDenom denom = box_reciprocal(box_denominator(rad));
     dim3 grid((unsigned)cdiv(C, 64), (unsigned)W);
-    hipLaunchKernelGGL((k_boxqf<KS, MODE>), grid, dim3(512), BOXQF_LDS_BYTES, r.st, srcW, gap, dstW, dstO, data, n, C, ld, rad,
+    hipLaunchKernelGGL((k_boxqf<KS, MODE, B>), grid, dim3(512), boxqf_lds_bytes(B), r.st, srcW, gap, dstW, dstO, data, n, C, ld, rad,
                        denom, sws_img, dws, ws_data, nanflag);
     LAUNCHCHK();
     return TRI_OK;
@@ -986,6 +989,15 @@ int launch_boxf(const Run& r, int ks, const float* srcW, const float* srcO, floa
             ((uintptr_t)srcW % 16 == 0) && ((uint64_t)(srcO - srcW) + (uint64_t)C * ld) * 4u < (1ull << 31) &&
             (uint64_t)n * (uint64_t)C * 4u < (1ull << 31)) {
             const unsigned gap = (unsigned)(srcO - srcW);
+            // blocks of 8 positions (two workgroups per CU) while the delay line leaves the registers for it
+            static const int b8 = [] { const char* e = getenv("TRI_FILTER_PIPE_F_B8"); return e ? atoi(e) : BOXQF_B8_DEFAULT; }();
+            if (b8 && 2 * rad >= 32 && 2 * rad < 56) {
+                switch (2 * rad / 8 * 8) {
+                    case 32: return launch_boxqf_ks<32, MODE, 8>(r, srcW, gap, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
+                    case 40: return launch_boxqf_ks<40, MODE, 8>(r, srcW, gap, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
+                    case 48: return launch_boxqf_ks<48, MODE, 8>(r, srcW, gap, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
+                }
+            }
             switch (kq) {
                 case 16: return launch_boxqf_ks<16, MODE>(r, srcW, gap, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
                 case 32: return launch_boxqf_ks<32, MODE>(r, srcW, gap, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
