@@ -579,7 +579,7 @@ int launch_boxp_spec_b(const Run& r, const float* srcData, const uint8_t* srcFla
 // K4q (kernels_boxpipe.hpp): register part of the delay lines for radius rad, 0 when it does not apply.
 // TRI_FILTER_NO_PIPE_T=1 keeps the K4r / LDS kernels.
 #ifndef BOXQ_MIN_2R
-#define BOXQ_MIN_2R 72
+#define BOXQ_MIN_2R 66
 #endif
 thread_local int g_boxq_override = -1;   // tests / benches: 0 = off, 1 = on wherever it applies
 static int boxq_pick_ks(int rad) {
@@ -649,7 +649,9 @@ int launch_colfilter(const Run& r, int srcmode, float* bufW, float* bufO, const 
         (uint64_t)n * (uint64_t)C * 4u < (1ull << 31))
         return launch_boxt_spec(r, boxr_pick_ks(rad), srcData, srcFlags, dstW, dstO, n, C, rad, denom);
     if (srcmode == 2 && !deferred_denom && !transposed_out && weights_are_01 && boxq_pick_ks(rad) > 0 && rad <= 107 &&
-        (g_boxq_override == 1 || 2 * rad >= BOXQ_MIN_2R) &&   // measured (1008 windows): K4r 13.4 / 19.1 / 23.0 / 23.7 ms at r = 21 / 32 / 43 / 54, K4q 19.1 / 20.0 / 20.4 / 20.5
+        // measured (1008 windows): K4r 13.4 / 19.1 / 21.9 / 22.2 / 20.0 / 23.0 / 23.7 ms at r = 21 / 32 / 33 / 36 / 40 / 43 / 54
+        // (r = 40: all 80 slots in registers, no LDS part), K4q 19.1 / 20.0 / 20.8 / 20.8 / 20.7 / 20.4 / 20.5
+        (g_boxq_override == 1 || (2 * rad >= BOXQ_MIN_2R && 2 * rad != 80)) &&
         n % 4 == 0 && (uint64_t)n * (uint64_t)C * 4u < (1ull << 31))
         return launch_boxq(r, boxq_pick_ks(rad), srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
     if (srcmode == 2 && !deferred_denom && !transposed_out && weights_are_01 && boxr_pick_ks_t(rad) > 0 &&
