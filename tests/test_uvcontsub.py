@@ -89,3 +89,41 @@ def test_gpu_config4_chain(gpu):
     f = oracle.uvcontsub_flagger(vis, f, **uv_kw)
     f = oracle.sum_threshold_flagger(vis, f, **st_kw) | f
     assert (got.cpu().numpy() == f).mean() >= 0.999
+
+
+UV_AB_SCRIPT = r'''
+import sys, hashlib
+sys.path.insert(0, %r)
+import numpy as np
+from tricolour_amd import flagging
+rs = np.random.RandomState(8)
+shape = (3, 2, 64, 512)
+x = np.linspace(0, 1, shape[3])
+vis = ((2 + np.cos(7 * x))[None, None, None, :] + 0.3 * rs.standard_normal(shape)
+       + 1j * 0.3 * rs.standard_normal(shape)).astype(np.complex64)
+vis[..., 100] += 5
+vis[2, 0, 10] += 3
+vis[0, 1, 5, 7] = np.nan
+flags = rs.uniform(size=shape) < 0.02
+flags[1, 1] = True
+out = flagging.uvcontsub_flagger(vis, flags, major_cycles=5, or_original_from_cycle=1, taylor_degrees=20, sigma=10.0)
+print("DIGEST", hashlib.sha1(np.packbits(out).tobytes()).hexdigest(), int(out.sum()))
+'''
+
+
+@pytest.mark.gpu
+def test_gpu_uvcontsub_vector_kernels_match_scalar(gpu):
+    """The four-samples-per-thread residual / apply kernels and the scalar ones (TRI_UV_SCALAR=1, read once per
+    process) give the same flags bit for bit."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    digests = []
+    for scalar in ("0", "1"):
+        env = dict(os.environ)
+        env["TRI_UV_SCALAR"] = scalar
+        p = subprocess.run([sys.executable, "-c", UV_AB_SCRIPT % ROOT], capture_output=True, text=True, env=env, timeout=600)
+        assert p.returncode == 0, p.stdout + p.stderr
+        digests.append([l for l in p.stdout.splitlines() if l.startswith("DIGEST")][0])
+    assert digests[0] == digests[1], digests

@@ -1175,6 +1175,41 @@ __global__ void k_uv_resid(const float2* __restrict__ vis, const uint8_t* __rest
     __syncthreads();
     if (threadIdx.x == 0 && s_cnt) atomicAdd(&cnt[cp], s_cnt);
 }
+// k_uv_resid, four channels per thread (F % 4 == 0, 16-byte aligned images): 2048 samples per workgroup
+__global__ void k_uv_resid4(const float2* __restrict__ vis, const uint8_t* __restrict__ rflags,
+                            const float2* __restrict__ smooth, float* __restrict__ absres,
+                            uint8_t* __restrict__ mflags, unsigned* __restrict__ cnt, int T, int F) {
+    __shared__ unsigned s_cnt;
+    const size_t N4 = (size_t)T * F / 4;
+    const int F4 = F / 4;
+    const size_t cp = blockIdx.y;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    unsigned nfl = 0;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const size_t i = (size_t)blockIdx.x * 512 + (size_t)u * 256 + threadIdx.x;   // group of 4 samples
+        if (i < N4) {
+            const int f4 = (int)(i % F4);
+            const float4* vp = reinterpret_cast<const float4*>(vis) + (cp * N4 + i) * 2;
+            const float4* sp = reinterpret_cast<const float4*>(smooth) + (cp * (size_t)F4 + f4) * 2;
+            const float4 z0 = vp[0], z1 = vp[1], s0 = sp[0], s1 = sp[1];
+            const unsigned fw = reinterpret_cast<const unsigned*>(rflags)[cp * N4 + i];
+            const float r0 = tri_hypotf(z0.x - s0.x, z0.y - s0.y), r1 = tri_hypotf(z0.z - s0.z, z0.w - s0.w);
+            const float r2 = tri_hypotf(z1.x - s1.x, z1.y - s1.y), r3 = tri_hypotf(z1.z - s1.z, z1.w - s1.w);
+            reinterpret_cast<float4*>(absres)[cp * N4 + i] = make_float4(r0, r1, r2, r3);
+            const unsigned fl = ((fw & 0xFFu) ? 1u : 0u) | ((fw & 0xFF00u) ? 0x100u : 0u) | ((fw & 0xFF0000u) ? 0x10000u : 0u) |
+                                ((fw & 0xFF000000u) ? 0x1000000u : 0u);
+            const unsigned nn = (isnan(r0) ? 1u : 0u) | (isnan(r1) ? 0x100u : 0u) | (isnan(r2) ? 0x10000u : 0u) | (isnan(r3) ? 0x1000000u : 0u);
+            reinterpret_cast<unsigned*>(mflags)[cp * N4 + i] = fl | nn;
+            nfl += __popc(fl);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) nfl += __shfl_down(nfl, o, 64);
+    if ((threadIdx.x & 63) == 0 && nfl) atomicAdd(&s_cnt, nfl);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) atomicAdd(&cnt[cp], s_cnt);
+}
 // (kept for the A/B of the difference image; the flagger forms | |residual| - median | inside the median kernels)
 __global__ void k_uv_diff(const float* __restrict__ absres, const double* __restrict__ med1,
                           float* __restrict__ diff, size_t N) {
@@ -1198,6 +1233,26 @@ __global__ void k_uv_apply(const float* __restrict__ absres, const double* __res
     bool nf = absres[cp * N + i] > thr;
     uint8_t old = rflags[cp * N + i];
     rflags[cp * N + i] = do_or ? (uint8_t)((old || nf) ? 1 : 0) : (uint8_t)(nf ? 1 : 0);
+}
+
+// k_uv_apply, four samples per thread (N % 4 == 0, 16-byte aligned images)
+__global__ void k_uv_apply4(const float* __restrict__ absres, const double* __restrict__ mad,
+                            const unsigned* __restrict__ cnt, uint8_t* __restrict__ rflags,
+                            float sigma, int do_or, size_t N4) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N4) return;
+    size_t cp = blockIdx.y;
+    if (cnt[cp] == (unsigned)(N4 * 4)) return;
+    const float thr = sigma * (float)mad[cp];
+    const float4 a = reinterpret_cast<const float4*>(absres)[cp * N4 + i];
+    unsigned* pf = reinterpret_cast<unsigned*>(rflags) + cp * N4 + i;
+    const unsigned nf = (a.x > thr ? 1u : 0u) | (a.y > thr ? 0x100u : 0u) | (a.z > thr ? 0x10000u : 0u) | (a.w > thr ? 0x1000000u : 0u);
+    if (do_or) {
+        const unsigned old = *pf;                               // (0 / 1 bytes: normalised at the start of the call)
+        if ((old | nf) != old) *pf = old | nf;
+    } else {
+        *pf = nf;
+    }
 }
 
 // ---------------------------------------------------------------------------

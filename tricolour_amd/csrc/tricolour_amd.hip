@@ -2149,7 +2149,12 @@ extern "C" int tri_uvcontsub_flagger(const void* vis_c64, const uint8_t* flags, 
             hipLaunchKernelGGL(k_uv_mean, dim3((unsigned)cdiv(F, 256), (unsigned)B), dim3(256), 0, st, v, rf, avg, T, F);
             hipLaunchKernelGGL(k_uv_lowpass, dim3((unsigned)B), dim3(256), 0, st, avg, smooth, F, K);
             // |vis - smooth|, the median flags and (in the same pass) the number of flagged samples per product
-            hipLaunchKernelGGL(k_uv_resid, dim3((unsigned)cdiv((int64_t)N, 2048), (unsigned)B), dim3(256), 0, st, v, rf, smooth, absres, mflags, cnt, T, F);
+            static const bool uv_scalar = [] { const char* e = getenv("TRI_UV_SCALAR"); return e && e[0] == '1'; }();   // (A/B, tests)
+            if (!uv_scalar && F % 4 == 0 && ((uintptr_t)v % 16 == 0) && ((uintptr_t)rf % 4 == 0) && ((uintptr_t)smooth % 16 == 0) &&
+                ((uintptr_t)absres % 16 == 0) && ((uintptr_t)mflags % 4 == 0))
+                hipLaunchKernelGGL(k_uv_resid4, dim3((unsigned)cdiv((int64_t)N, 2048), (unsigned)B), dim3(256), 0, st, v, rf, smooth, absres, mflags, cnt, T, F);
+            else
+                hipLaunchKernelGGL(k_uv_resid, dim3((unsigned)cdiv((int64_t)N, 2048), (unsigned)B), dim3(256), 0, st, v, rf, smooth, absres, mflags, cnt, T, F);
             LAUNCHCHK();
             // nanmedian over the unflagged, non-NaN residuals of each product (:1061), then the median of
             // | |residual| - median | (:1064-1066) straight from the residual image
@@ -2157,7 +2162,10 @@ extern "C" int tri_uvcontsub_flagger(const void* vis_c64, const uint8_t* flags, 
             if (rcm) return rcm;
             rcm = launch_median_big(st, absres, mflags, N, B, med1, mad, mpar, ghist, gcand, vec);
             if (rcm) return rcm;
-            hipLaunchKernelGGL(k_uv_apply, dim3((unsigned)cdiv((int64_t)N, 256), (unsigned)B), dim3(256), 0, st, absres, mad, cnt, rf, (float)sigma, mi >= or_original_from_cycle ? 1 : 0, N);
+            if (!uv_scalar && N % 4 == 0 && ((uintptr_t)absres % 16 == 0) && ((uintptr_t)rf % 4 == 0))
+                hipLaunchKernelGGL(k_uv_apply4, dim3((unsigned)cdiv((int64_t)(N / 4), 256), (unsigned)B), dim3(256), 0, st, absres, mad, cnt, rf, (float)sigma, mi >= or_original_from_cycle ? 1 : 0, N / 4);
+            else
+                hipLaunchKernelGGL(k_uv_apply, dim3((unsigned)cdiv((int64_t)N, 256), (unsigned)B), dim3(256), 0, st, absres, mad, cnt, rf, (float)sigma, mi >= or_original_from_cycle ? 1 : 0, N);
             LAUNCHCHK();
         }
     }
