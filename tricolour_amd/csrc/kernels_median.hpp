@@ -805,8 +805,21 @@ k_medbig_select(const float* __restrict__ data, const uint8_t* __restrict__ flag
     if (p.mode == 1) {
         const unsigned ncand = p.ncand;
         const unsigned* cand = gcand + w * MEDBIG_CAND;          // a few tens of KB: L2-resident for the three passes
-        st = select3(hist, sh, [&](auto&& visit) { for (unsigned i = tid; i < ncand; i += 256) visit(cand[i]); },
-                     (long long)((p.total >> 1) - p.exc));
+        // (16-byte groups, eight in flight per thread: the list is read three times by ONE workgroup)
+        st = select3(hist, sh, [&](auto&& visit) {
+            const uint4* g4 = reinterpret_cast<const uint4*>(cand);
+            const unsigned n4 = ncand >> 2;
+            unsigned i = tid;
+            for (; i + 256 * 7 < n4; i += 256 * 8) {
+                uint4 q[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) q[u] = g4[i + 256 * u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { visit(q[u].x); visit(q[u].y); visit(q[u].z); visit(q[u].w); }
+            }
+            for (; i < n4; i += 256) { const uint4 q = g4[i]; visit(q.x); visit(q.y); visit(q.z); visit(q.w); }
+            if ((unsigned)tid < (ncand & 3u)) visit(cand[(n4 << 2) + tid]);
+        }, (long long)((p.total >> 1) - p.exc));
         st.n = p.total;
         below1 = p.below1;
     } else {
