@@ -802,6 +802,12 @@ k_medbig_select(const float* __restrict__ data, const uint8_t* __restrict__ flag
     const int tid = threadIdx.x;
     Sel3State st;
     unsigned below1 = 1;
+    if (p.total == 0) {
+        // the histogram pass saw no unflagged sample at all (a fully flagged product, e.g. an autocorrelation
+        // after flag_autos): NaN, without one workgroup walking the whole window three times for nothing
+        if (tid == 0) med[w] = __longlong_as_double(0x7FF8000000000000LL);
+        return;
+    }
     if (p.mode == 1) {
         const unsigned ncand = p.ncand;
         const unsigned* cand = gcand + w * MEDBIG_CAND;          // a few tens of KB: L2-resident for the three passes
