@@ -24,8 +24,10 @@ flags back over RCCL (tricolour_amd.distributed), which is how a single-root dat
 before any GPU call and relays rank 0's line.
 
 Prints ONE JSON line (rank 0): metric / value = whole-job Mvis/s with inputs already resident in HBM, plus
-  "roofline"      list: the fused SumThreshold column kernel and the box-filter stages, each timed live with
-                  HIP events on its launch stream in the step's own launch geometry;
+  "roofline"      ONE object: the kernel with the largest share of the step (the fused frequency-axis box
+                  filter stage), timed live with HIP events on its launch stream in the step's own launch
+                  geometry; "roofline_kernels" lists every kernel measured that way (SumThreshold included);
+  "parity_check"  the HIP path on the windows the cpu_baseline leg fed the oracle: {windows, vis, mismatches};
   "cpu_baseline"  the CPU oracle (a C restatement of the reference's numba path -- numba itself cannot run
                   here) on a bounded sample of the same workload on this box's host cores (rank 0, N=1);
   "other_params"  the same slab with the other shipped parameter sets (slab workload, N=1).
@@ -70,6 +72,9 @@ ST_BYTES_PER_SAMPLE = 5  # fused SumThreshold pass: 4 B residual in + 1 B flag o
 # 2 arrays x (4 R + 4 W) = 16 B/sample; the fused frequency stage also reads the amplitudes (4 B) and writes one
 # image instead of two: 8 R + 4 R + 4 W = 16 B/sample
 BOX_BYTES_PER_SAMPLE = 16
+# the time-axis stage builds its weight image from the packed flag words (1 B/sample) instead of a 4 B float
+# image: 4 B data + 1 B flags read, 2 x 4 B written = 13 B/sample actually required (PMC 0.875 x 16)
+BOX_TIME_BYTES_PER_SAMPLE = 13
 
 
 def box_radius(sigma):
@@ -125,7 +130,12 @@ def cpu_baseline(kw, T, F, seconds_budget=25.0, chain=None):
     workload.  `chain`: also run the cheap steps and uvcontsub (numpy restatements) in front."""
     from oracle import oracle
     oracle.set_modes(oracle.POW_SQMUL, oracle.INTERP_F64)
-    cores = min(os.cpu_count() or 1, 16)
+    nproc = os.cpu_count() or 1
+    try:
+        nproc = len(os.sched_getaffinity(0))     # the cores this process may actually run on
+    except (AttributeError, OSError):
+        pass
+    cores = int(os.environ.get("TRI_BENCH_CPU_THREADS", nproc))
 
     def run(vis, flags, threads):
         t0 = time.time()
@@ -135,28 +145,53 @@ def cpu_baseline(kw, T, F, seconds_budget=25.0, chain=None):
             out = oracle.sum_threshold_flagger(vis, f, n_threads=threads, **kw)
             out |= f
         else:
-            oracle.sum_threshold_flagger(vis, flags, n_threads=threads, **kw)
-        return time.time() - t0
+            out = oracle.sum_threshold_flagger(vis, flags, n_threads=threads, **kw)
+        return time.time() - t0, out
 
-    # calibrate on one window with one thread, then size the sample
+    # calibrate on one window with one thread, then size the sample: every thread gets the same number of
+    # windows, the whole sample stays within ~seconds_budget of wall time and 128 windows (4.3 GB of vis)
     vis, flags = synth_host_windows(1, T, F)
-    t1 = run(vis, flags, 1)
-    per_thread = max(1, int(seconds_budget / max(t1, 1e-3)))
-    nwin = cores * min(per_thread, 2)
-    if t1 > seconds_budget:
-        nwin = cores
+    t1, _ = run(vis, flags, 1)
+    per_thread = max(1, min(2, int(seconds_budget / max(t1, 1e-3))))
+    nwin = cores * per_thread
+    while nwin > 128 and per_thread > 1:
+        per_thread -= 1
+        nwin = cores * per_thread
+    nwin = min(nwin, 256)
     vis, flags = synth_host_windows(nwin, T, F)
-    dt = run(vis, flags, cores)
+    dt, out = run(vis, flags, cores)
     what = "chain (flag_nans_zeros, uvcontsub, sum_threshold)" if chain is not None else "same kwargs"
-    return dict(value=round(nwin * T * F / dt / 1e6, 3), unit="Mvis/s", cores=cores, kind="port",
-                sample="%d windows of %dx%d (1 corr), %s, %.1f s; C restatement of the "
-                       "reference numba path (oracle/), OpenMP over windows" % (nwin, T, F, what, dt))
+    res = dict(value=round(nwin * T * F / dt / 1e6, 3), unit="Mvis/s", cores=cores, nproc=nproc, kind="port",
+               sample="%d windows of %dx%d (1 corr), %s, %.1f s on %d threads (host has %d cores); C restatement "
+                      "of the reference numba path (oracle/), OpenMP over windows" % (nwin, T, F, what, dt, cores, nproc))
+    return res, vis, flags, out
+
+
+def parity_check(torch, tricolour_amd, device, kw, vis, flags, expected, chain=None):
+    """The HIP path on the very windows the cpu_baseline leg fed the oracle (outside the timed region; the
+    oracle is the checker, never the thing measured).  Bit-exact is the bar for sum_threshold_flagger; the chain
+    goes through uvcontsub's FFT, whose summation order differs from numpy's (agreement rate)."""
+    dv = torch.from_numpy(vis).to(device)
+    df = torch.from_numpy(flags).to(device)
+    if chain is not None:
+        f = tricolour_amd.flag_nans_and_zeros(dv, df)
+        f = tricolour_amd.uvcontsub_flagger(dv, f, **chain)
+        got = tricolour_amd.sum_threshold_flagger(dv, f, **kw) | f
+    else:
+        got = tricolour_amd.sum_threshold_flagger(dv, df, **kw)
+    torch.cuda.synchronize()
+    got = got.cpu().numpy()
+    bad = int((got != expected).sum())
+    return dict(windows=int(vis.shape[0] * vis.shape[1]), vis=int(vis.size), mismatches=bad,
+                flagged_oracle=int(expected.sum()), flagged_hip=int(got.sum()),
+                expected="bit-exact" if chain is None else ">= 99.9 % agreement (uvcontsub FFT order, SURVEY 8f-2)",
+                checker="oracle/ (C restatement of the reference numba path), same windows and kwargs as cpu_baseline")
 
 
 def _pmc_traffic(name, samples):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes of the same launch geometry
     (FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE); bench.py cannot collect counters itself."""
-    for fn in ("r02_pmc_%s.json" % name, "r01_pmc_%s.json" % name):
+    for fn in ("r03_pmc_%s.json" % name, "r02_pmc_%s.json" % name):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
             if pmc.get("samples_per_launch") == samples:
@@ -221,11 +256,13 @@ def roofline_boxfilter(torch, device, T, F, kw, nwin):
              (1, box_radius(swf), "frequency-axis stage fused with the masked division (k_boxf), last background pass")]
     if nit > 1:
         cases.insert(1, (1, box_radius(nit * swf), "frequency-axis stage fused with the masked division (k_boxqf), first background iteration"))
+    dominant = 1        # the fused frequency-axis stage: the largest share of the step's kernel time
     samples = nwin * T * F
     out = []
-    for stage, rad, what in cases:
+    for ci, (stage, rad, what) in enumerate(cases):
         if rad <= 0:
             continue
+        bps = BOX_TIME_BYTES_PER_SAMPLE if stage == 0 else BOX_BYTES_PER_SAMPLE
         src = f4 if stage == 0 else wimg
         try:
             for reps in (1, 4):
@@ -234,14 +271,14 @@ def roofline_boxfilter(torch, device, T, F, kw, nwin):
         except (NotImplementedError, ValueError) as e:
             out.append(dict(bound="hbm", kernel="box filter %s, r = %d" % (what, rad), error=str(e)))
             continue
-        achieved = samples * BOX_BYTES_PER_SAMPLE / (ms.value * 1e-3) / 1e9
+        achieved = samples * bps / (ms.value * 1e-3) / 1e9
         traffic, tsrc = _pmc_traffic("boxfilter_s%d_r%d" % (stage, rad), samples)
         out.append(dict(bound="hbm", kernel="box filter %s, r = %d" % (what, rad),
                         achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=tsrc,
-                        algorithmic_bytes_per_launch=samples * BOX_BYTES_PER_SAMPLE,
-                        bytes_per_sample=BOX_BYTES_PER_SAMPLE, samples_per_launch=samples,
-                        ms_per_launch=round(ms.value, 4)))
+                        algorithmic_bytes_per_launch=samples * bps,
+                        bytes_per_sample=bps, samples_per_launch=samples,
+                        ms_per_launch=round(ms.value, 4), dominant=(ci == dominant)))
     return out
 
 
@@ -424,6 +461,7 @@ def main():
     ap.add_argument("--scatter-timeout", type=int, default=240, help="seconds the N > 1 scatter / gather leg may take")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-parity-check", action="store_true")
     ap.add_argument("--no-other-params", action="store_true")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the per-kernel roofline legs (what the rocprofv3 --pmc passes of profiles/ wrap)")
@@ -462,7 +500,7 @@ def main():
     T = args.time or (512 if wl == "ska" else 1024)
     F = args.chan or (65536 if wl == "ska" else 4096)
     nbl = args.bl or int(os.environ.get("TRI_BENCH_BL", {"slab": "252", "chain": "84", "ska": "32"}[wl]))
-    pname = args.params or ("defaults" if wl == "ska" else "stage1")
+    pname = args.params or "stage1"          # stage 1 is the headline parameter set
     steps = args.steps if args.steps is not None else {"slab": 3, "chain": 1, "ska": 64}[wl]
     warmup = args.warmup if args.warmup is not None else {"slab": 2, "chain": 1, "ska": 2}[wl]
     kw = PARAM_SETS[pname]
@@ -496,7 +534,7 @@ def main():
 
     if args.roofline_only:
         nwin = min(nbl * ncorr, 1008 if wl != "ska" else 64)
-        print(json.dumps({"roofline": [roofline_sumthreshold(torch, device, T, F, kw, nwin)] +
+        print(json.dumps({"roofline_kernels": [roofline_sumthreshold(torch, device, T, F, kw, nwin)] +
                           roofline_boxfilter(torch, device, T, F, kw, nwin)}))
         return
 
@@ -607,10 +645,24 @@ def main():
     if rank == 0:
         nwin = min(nbl * ncorr, 1008 if wl != "ska" else 64)
         if not args.no_roofline:
-            res["roofline"] = [roofline_sumthreshold(torch, device, T, F, kw, nwin)] + \
+            kernels = [roofline_sumthreshold(torch, device, T, F, kw, nwin)] + \
                 roofline_boxfilter(torch, device, T, F, kw, nwin)
+            # "roofline" = ONE object: the kernel with the largest share of the timed step -- the box-filter
+            # stage that runs at the most radii of the parameter set (the fused frequency-axis stage at its
+            # largest radius when there are several background iterations, else the time-axis stage);
+            # every measured kernel, the SumThreshold kernel among them, is under "roofline_kernels"
+            timed = [k for k in kernels if "frac" in k]
+            dom = [k for k in timed if k.get("dominant")] or timed[1:2] or timed
+            if dom:
+                res["roofline"] = {k: v for k, v in dom[0].items() if k != "dominant"}
+            res["roofline_kernels"] = [{k: v for k, v in e.items() if k != "dominant"} for e in kernels]
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(kw, T, F, chain=UVCONTSUB_KW if wl == "chain" else None)
+            chain_kw = UVCONTSUB_KW if wl == "chain" else None
+            res["cpu_baseline"], hv, hf, hexp = cpu_baseline(kw, T, F, chain=chain_kw)
+            if not args.no_parity_check:
+                res["parity_check"] = parity_check(torch, tricolour_amd, device, kw, hv, hf, hexp, chain=chain_kw)
+                flagging.release_workspace()
+            del hv, hf, hexp
         torch.cuda.empty_cache()
     leg_failed = False
     # N > 1: the scatter -> flag -> gather leg comes last, under a watchdog -- a stuck point-to-point transfer
@@ -623,7 +675,7 @@ def main():
                 res["scatter"] = dict(error="no completion within %d s" % args.scatter_timeout)
                 print(json.dumps(res))
                 sys.stdout.flush()
-            os._exit(0)
+            os._exit(3)                   # a stuck leg is a failure: the launcher and the driver must see it
         timer = threading.Timer(args.scatter_timeout, give_up)
         timer.daemon = True
         timer.start()
@@ -639,7 +691,13 @@ def main():
         print(json.dumps(res))
         sys.stdout.flush()
     if leg_failed:
-        os._exit(0)                   # peers may be stuck in the failed leg's transfers: no further collective
+        # peers may be stuck in the failed leg's transfers: no further collective; abort the group so they
+        # fail fast instead of waiting for the collective timeout, and leave with a non-zero code
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
+        os._exit(3)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

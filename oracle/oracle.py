@@ -398,15 +398,19 @@ def apply_static_mask(flag, ubl, antspos, masks, chan_freqs, chan_widths,
 
 
 def uvcontsub_flagger(vis, flags, major_cycles=5, or_original_from_cycle=1,
-                      taylor_degrees=20, sigma=5):
+                      taylor_degrees=20, sigma=5, dump=False):
     """NumPy restatement of flagging.py:989-1073 (the reference routine is
-    itself plain NumPy; results follow the running NumPy's FFT precision)."""
+    itself plain NumPy; results follow the running NumPy's FFT precision).
+    dump=True: also returns the last cycle's |vis - smooth| and the per-product
+    threshold sigma * mad (the tests use them to tell borderline samples)."""
     import warnings
     if vis.shape != flags.shape:
         raise ValueError("vis and flags must have the same shape")
     nbl, ncorr, ntime, nfreq = vis.shape
     v = vis.reshape(nbl * ncorr, ntime, nfreq)
     res = flags.reshape(nbl * ncorr, ntime, nfreq).astype(bool).copy()
+    last_abs = np.full(v.shape, np.nan)
+    last_thr = np.full(v.shape[0], np.nan)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         for mi in range(major_cycles):
@@ -428,6 +432,10 @@ def uvcontsub_flagger(vis, flags, major_cycles=5, or_original_from_cycle=1,
                 mad = np.nanmedian(np.abs(diff))
                 new = absres > sigma * mad
                 res[cp] = (start[cp] | new) if mi >= or_original_from_cycle else new
+                last_abs[cp] = absres
+                last_thr[cp] = sigma * mad
+    if dump:
+        return res.reshape(nbl, ncorr, ntime, nfreq), dict(absres=last_abs, thr=last_thr)
     return res.reshape(nbl, ncorr, ntime, nfreq)
 
 

@@ -549,16 +549,27 @@ def test_full_size_window_vs_oracle(gpu, oracle):
     assert nbad == 0, "%d of %d flags differ" % (nbad, out.size)
 
 
-# The shipped strategy file's two heaviest parameter sets (conf/default.yaml:20-35 and :59-73),
+# Every sum_threshold parameter set of the shipped strategy file (conf/default.yaml:17-35, 59-105),
 # restated here because the reference tree does not travel to the GPU box.
 SHIPPED_KWARGS = {
-    # "background_flags": box radii [54,43] [43,34] [32,25] [21,17] [10,8] (lane-per-stage and
-    # four-ring filters on 1024- / 4096-long lines), two of the five major iterations
+    # "background_flags": box radii [54,43] [43,34] [32,25] [21,17] [10,8], all five major iterations
     "stage1": dict(outlier_nsigma=10, windows_time=[1, 2, 4, 8], windows_freq=[1, 2, 4, 8],
                    background_reject=2.0, background_iterations=5, spike_width_time=12.5,
                    spike_width_freq=10.0, time_extend=3, freq_extend=3, freq_chunks=10,
                    average_freq=1, flag_all_time_frac=0.6, flag_all_freq_frac=0.8, rho=1.3,
-                   num_major_iterations=2),
+                   num_major_iterations=5),
+    # "final_st_broad" (:74-89): time radii 28 / 22 / 16 / 11 / 5, frequency radii as stage 1
+    "broad": dict(outlier_nsigma=10, windows_time=[1, 2, 4, 8], windows_freq=[1, 2, 4, 8],
+                  background_reject=2.0, background_iterations=5, spike_width_time=6.5,
+                  spike_width_freq=10.0, time_extend=3, freq_extend=3, freq_chunks=10,
+                  average_freq=1, flag_all_time_frac=0.6, flag_all_freq_frac=0.8, rho=1.3,
+                  num_major_iterations=1),
+    # "final_st_narrow" (:90-105): spike_width_time arrives as a Python int (2): time radii 8 / 6 / 5 / 3 / 1
+    "narrow": dict(outlier_nsigma=10, windows_time=[1, 2, 4, 8], windows_freq=[1, 2, 4, 8],
+                   background_reject=2.0, background_iterations=5, spike_width_time=2,
+                   spike_width_freq=10.0, time_extend=3, freq_extend=3, freq_chunks=10,
+                   average_freq=1, flag_all_time_frac=0.6, flag_all_freq_frac=0.8, rho=1.3,
+                   num_major_iterations=1),
     # "final_st_very_broad": frequency radii 277 / 221 / 166 / 110 / 55 (the first three take the
     # in-place multi-pass filter by the default route), frequency windows 32...128 (generic
     # SumThreshold kernel on full lines)
@@ -596,7 +607,7 @@ def test_full_size_shipped_kwargs_vs_oracle(gpu, oracle, name):
     """One 1024 x 4096 window pair per shipped parameter set through the DEFAULT kernel
     routes, flags and the six last-iteration intermediates bit-for-bit against the
     canonical oracle (flagging.py:422-466, 610-681)."""
-    vis, flags = _full_size_inputs(7 if name == "stage1" else 8)
+    vis, flags = _full_size_inputs({"stage1": 7, "very_broad": 8}.get(name, 9 + len(name)))
     kw = SHIPPED_KWARGS[name]
     dbg = {}
     out = gpu.sum_threshold_flagger(vis, flags, _debug=dbg, **kw)
@@ -615,6 +626,30 @@ def test_full_size_shipped_kwargs_vs_oracle(gpu, oracle, name):
         report.append("out: %d of %d flags differ" % (bad, out.size))
     assert not report, "%s: %s" % (name, "; ".join(report))
     assert 0 < out.mean() < 1
+
+
+def test_inf_nan_visibility_is_flagged_on_the_cached_amplitude_route(gpu, oracle):
+    """flagging.py:777-781: the final `isnan(in_data)` is of the complex visibility -- either part NaN.  A sample
+    with one infinite and one NaN part has amplitude +inf (C99 hypot), so only that final test flags it.  F is a
+    multiple of 16 (the cached-amplitude route, k_amplitude4's NaN bitmap); the samples are pre-flagged so that the
+    infinite amplitude never enters a running sum (unflagged infinities are undefined in the reference itself)."""
+    rs = np.random.RandomState(5)
+    shape = (2, 2, 32, 64)
+    vis = (rs.standard_normal(shape) + 1j * rs.standard_normal(shape)).astype(np.complex64)
+    vis[..., 20] *= 7
+    flags = rs.uniform(size=shape) < 0.03
+    special = [((0, 0, 3, 5), complex(np.inf, np.nan)), ((0, 1, 9, 17), complex(np.nan, -np.inf)),
+               ((1, 0, 30, 63), complex(np.nan, 1.0)), ((1, 1, 0, 0), complex(2.0, np.nan)),
+               ((1, 1, 31, 48), complex(np.nan, np.nan))]
+    for idx, z in special:
+        vis.real[idx] = z.real
+        vis.imag[idx] = z.imag
+        flags[idx] = True
+    for kw in (dict(num_major_iterations=1), dict(num_major_iterations=3, background_iterations=2)):
+        exp = oracle.sum_threshold_flagger(vis, flags, **kw)
+        got = gpu.sum_threshold_flagger(vis, flags, **kw)
+        assert all(exp[idx] for idx, _ in special)
+        assert np.array_equal(got, exp), "%d flags differ" % (got != exp).sum()
 
 
 def test_two_stream_schedule_vs_oracle(gpu, oracle):

@@ -55,6 +55,56 @@ def test_gpu_uvcontsub_agreement(gpu):
     assert (got == exp).mean() >= 0.9995
 
 
+# conf/default.yaml:37-45 and :106-112 (restated: the reference tree does not travel to the GPU box)
+UV_SHIPPED = {
+    "residual_flag_initial": dict(major_cycles=7, or_original_from_cycle=1, taylor_degrees=20, sigma=15.0),
+    "residual_flag_final": dict(major_cycles=10, or_original_from_cycle=0, taylor_degrees=25, sigma=13.0),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(UV_SHIPPED))
+def test_gpu_uvcontsub_shipped_kwargs_mismatches_are_borderline(gpu, name):
+    """Both shipped uvcontsub parameter sets.  NumPy's float64 FFT / pairwise nanmean cannot be reproduced bit for
+    bit, so the claim is made precise: cycle by cycle, from the SAME starting flags, every flag
+    that differs from the oracle's sits on a sample whose |vis - smooth| lies within rounding of the threshold
+    sigma * mad; the number of such samples is printed.  The free-running chains must still agree >= 99.9 %."""
+    from oracle import oracle
+    from tricolour_amd import flagging
+    kw = UV_SHIPPED[name]
+    rs = np.random.RandomState(31 + len(name))
+    shape = (3, 2, 96, 512)
+    x = np.linspace(0, 1, shape[3])
+    vis = ((2 + np.cos(7 * x) + 0.5 * np.sin(23 * x))[None, None, None, :] + 0.3 * rs.standard_normal(shape)
+           + 1j * (0.2 * x[None, None, None, :] + 0.3 * rs.standard_normal(shape))).astype(np.complex64)
+    vis[..., 100] += 5
+    vis[..., 300:304] += 1.0                       # faint: near the threshold in later cycles
+    vis[2, 0, 10] += 3
+    vis[0, 1, 5, 7] = np.nan
+    flags = rs.uniform(size=shape) < 0.02
+    flags[1, 1] = True                             # a fully flagged product stays untouched
+    cur = flags.copy()
+    total_bad = 0
+    for mi in range(kw["major_cycles"]):
+        one = dict(kw, major_cycles=1, or_original_from_cycle=0 if mi >= kw["or_original_from_cycle"] else 1)
+        exp, d = oracle.uvcontsub_flagger(vis, cur, dump=True, **one)
+        got = flagging.uvcontsub_flagger(vis, cur, **one)
+        bad = got != exp
+        if bad.any():
+            thr = np.broadcast_to(d["thr"].reshape(shape[0], shape[1], 1, 1), shape)
+            rel = np.abs(d["absres"].reshape(shape) - thr)[bad] / thr[bad]
+            assert rel.max() < 1e-5, "cycle %d: %d flags differ, farthest %.3g of the threshold away" % (mi, bad.sum(), rel.max())
+        total_bad += int(bad.sum())
+        cur = exp
+    free = flagging.uvcontsub_flagger(vis, flags, **kw)
+    ref = oracle.uvcontsub_flagger(vis, flags, **kw)
+    nfree = int((free != ref).sum())
+    print("%s: %d borderline flags over %d lock-step cycles, %d of %d differ free-running"
+          % (name, total_bad, kw["major_cycles"], nfree, free.size))
+    assert nfree <= 1e-3 * free.size
+    assert free[1, 1].all()
+
+
 @pytest.mark.gpu
 def test_gpu_config4_chain(gpu):
     """BASELINE config 4 in miniature: static mask -> flag_autos -> uvcontsub

@@ -524,14 +524,21 @@ __global__ void k_amplitude4(const void* __restrict__ vis, float* __restrict__ a
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // group of 4 samples, flat over the batch
     if (i >= n4) return;
     float a[4];
+    // vn: the reference's final isnan(in_data) (flagging.py:777-781) -- of the VISIBILITY, i.e. either part
+    // NaN; it differs from isnan(amplitude) for a sample with one infinite and one NaN part, whose
+    // amplitude is +inf (C99 hypot) and so is NOT flagged by _average_freq (flagging.py:856-861)
+    bool vn[4];
     if (VD == TRI_VIS_C64) {
         float4 z0 = reinterpret_cast<const float4*>(vis)[2 * i];
         float4 z1 = reinterpret_cast<const float4*>(vis)[2 * i + 1];
         a[0] = tri_hypotf(z0.x, z0.y); a[1] = tri_hypotf(z0.z, z0.w);
         a[2] = tri_hypotf(z1.x, z1.y); a[3] = tri_hypotf(z1.z, z1.w);
+        vn[0] = isnan(z0.x) || isnan(z0.y); vn[1] = isnan(z0.z) || isnan(z0.w);
+        vn[2] = isnan(z1.x) || isnan(z1.y); vn[3] = isnan(z1.z) || isnan(z1.w);
     } else {
         float4 z = reinterpret_cast<const float4*>(vis)[i];
         a[0] = fabsf(z.x); a[1] = fabsf(z.y); a[2] = fabsf(z.z); a[3] = fabsf(z.w);
+        vn[0] = isnan(z.x); vn[1] = isnan(z.y); vn[2] = isnan(z.z); vn[3] = isnan(z.w);
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) a[k] = (0.0f + a[k]) / 1.0f;   // factor 1: sum = 0 + a, count 1 (flagging.py:858-870)
@@ -540,8 +547,8 @@ __global__ void k_amplitude4(const void* __restrict__ vis, float* __restrict__ a
                           (isnan(a[3]) ? 0x1000000u : 0u);
     if (nanb) reinterpret_cast<unsigned*>(iter)[i] |= nanb;
     // NaN bitmap, 16 samples (4 neighbouring threads; n4 % 4 == 0) per word: k_final16's NaN test
-    // then costs 1/8 B per sample instead of re-reading the amplitudes
-    unsigned m = ((isnan(a[0]) ? 1u : 0u) | (isnan(a[1]) ? 2u : 0u) | (isnan(a[2]) ? 4u : 0u) | (isnan(a[3]) ? 8u : 0u)) << (4 * (threadIdx.x & 3));
+    // then costs 1/8 B per sample instead of re-reading the visibilities
+    unsigned m = ((vn[0] ? 1u : 0u) | (vn[1] ? 2u : 0u) | (vn[2] ? 4u : 0u) | (vn[3] ? 8u : 0u)) << (4 * (threadIdx.x & 3));
     m |= __shfl_xor(m, 1, 64);
     m |= __shfl_xor(m, 2, 64);
     if ((threadIdx.x & 3) == 0) nanmask[i >> 2] = (uint16_t)m;
