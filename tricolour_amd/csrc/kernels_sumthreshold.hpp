@@ -117,12 +117,20 @@ k_colst_dyn(const float* __restrict__ data, const double* __restrict__ med,
 
 // ---------------------------------------------------------------------------
 // K7p  The dynamic cascade as a STAGE PIPELINE across the waves of a workgroup (any window list of up to
-// eight windows whose rings fit LDS: final_st_very_broad's 32, 48, 64, 128).
+// eight windows: final_st_very_broad's 32, 48, 64, 128).
 // k_colst_dyn keeps every thread's prefix rings in global memory -- 2176 bytes per thread for those four
 // windows, 1.1 GB across the resident threads, re-read every w positions: the kernel is bound by that HBM
 // traffic (0.11 TB/s of algorithmic bytes).  Here a workgroup of nw waves owns 64 lines (lane = column):
-// wave j runs ONLY window j, its ring of w_j float64 prefix values per lane lives in LDS ([slot][lane]),
-// and the per-position (pos, neg) bits travel from stage to stage through a circular LDS byte buffer.
+// wave j runs ONLY window j, and the per-position (pos, neg) bits travel from stage to stage through a
+// circular LDS byte buffer.
+// NO PREFIX RING (round 3): S_k = cum[k + w] - cum[k] needs the prefix sum of w positions ago.  cum[k] is
+// a deterministic function of the clamped values c_0 .. c_{k-1} added in order, so a SECOND accumulator that
+// runs w positions behind the first and is fed the same clamped values reproduces cum[k] bit for bit:
+// S_k = lead - lag.  The lagging accumulator re-reads x_k from memory (a row this workgroup streamed w
+// positions ago: L2 / Infinity Cache) and re-derives the clamp from the flag byte of position k as it
+// stands just before this stage emits position k -- the stages before are final there and nothing else
+// has touched it, so it is the very byte the stage saw when it ingested x_k.  What used to be 139 KB of
+// float64 rings per workgroup (one wave per SIMD) is two registers; LDS only holds the flag bytes.
 // Positions are processed in blocks of 16 with one workgroup barrier per block; stage j + 1 runs
 // ceil((w_j - 1) / 16) + 1 blocks behind stage j, i.e. behind every position stage j may still flag,
 // so its clamp sees exactly the flags of the stages before it -- as in K7 / flagging.py:638-674.  Every
@@ -130,15 +138,13 @@ k_colst_dyn(const float* __restrict__ data, const double* __restrict__ med,
 // grid (ceil(C / 64), G, W), block 64 * nw, dynamic LDS stp_lds_bytes(sw)
 // ---------------------------------------------------------------------------
 #define STP_B 16
-struct StPipe { int lag[TRI_MAX_WINDOWS + 1]; int accn; int ringoff_b[TRI_MAX_WINDOWS]; };
+struct StPipe { int lag[TRI_MAX_WINDOWS + 1]; int accn; };
 __host__ inline StPipe stp_plan(const StWin& sw) {
     StPipe pp{};
-    int lag = 0, off = 0;
+    int lag = 0;
     for (int j = 0; j < sw.nw; j++) {
         pp.lag[j] = lag;
-        pp.ringoff_b[j] = off;
         lag += (sw.w[j] - 1 + STP_B - 1) / STP_B + 1;
-        off += sw.w[j] * 64 * 8;
     }
     pp.lag[sw.nw] = lag;
     pp.accn = (lag + 2) * STP_B;
@@ -146,10 +152,13 @@ __host__ inline StPipe stp_plan(const StWin& sw) {
 }
 __host__ inline size_t stp_lds_bytes(const StWin& sw) {
     const StPipe pp = stp_plan(sw);
-    return (size_t)sw.ringtot * 64 * 8 + (size_t)pp.accn * 64;
+    return (size_t)pp.accn * 64;
 }
 
-__global__ void __launch_bounds__(512)
+#ifndef STP_MINWAVES
+#define STP_MINWAVES 1                  // (tuning: minimum waves per SIMD the register allocation must allow)
+#endif
+__global__ void __launch_bounds__(512, STP_MINWAVES)
 k_colst_pipe(const float* __restrict__ data, const double* __restrict__ med, uint8_t* __restrict__ out,
              const int64_t* __restrict__ chunk_ends, StWin sw, StPipe pp, double thr_scale, int L, int C, int G,
              size_t ws_data, size_t ws_out) {
@@ -169,11 +178,9 @@ k_colst_pipe(const float* __restrict__ data, const double* __restrict__ med, uin
     const int p1 = min(c1 + sw.maxw - 1, L);
     const int Lp = p1 - p0;
     const int w = sw.w[j];
-    double* ring = reinterpret_cast<double*>(reinterpret_cast<char*>(stp_lds) + pp.ringoff_b[j]) + lane;   // [slot][64]
-    uint8_t* acc = reinterpret_cast<uint8_t*>(stp_lds) + (size_t)sw.ringtot * 64 * 8 + lane;             // [position % accn][64]
+    uint8_t* acc = reinterpret_cast<uint8_t*>(stp_lds) + lane; // [position % accn][64]
     const int accn = pp.accn;
     for (int s = threadIdx.x; s < accn * 64; s += blockDim.x) (acc - lane)[s] = 0;
-    ring[0] = 0.0;                                             // cum[0] = 0 in slot 0
     // flagging.py:622-628
     const float mad = (float)med[(win * (size_t)C + cc) * G + g];
     const float thr0 = isnan(mad) ? INFINITY : (float)((double)mad * thr_scale);
@@ -182,15 +189,15 @@ k_colst_pipe(const float* __restrict__ data, const double* __restrict__ med, uin
     const float* x = data + win * ws_data + cc;
     uint8_t* o = out + win * ws_out + c;
     const size_t Cs = (size_t)C;
-    double cumlast = 0.0;
+    double cumlast = 0.0;                                      // cum[i + 1] after ingesting position i
+    double cumlag = 0.0;                                       // cum[e], e = i + 1 - w: the same sum, w positions behind
     int sincep = 1 << 30, sincen = 1 << 30;
-    int slot = 1 % w;                                          // ring slot of prefix i + 1 (next to write / oldest to read)
     int apos = 0;                                              // acc index of ingest position i
     int aemit = (accn - (w - 1) % accn) % accn;                // acc index of emit position e = i + 1 - w
     const int lag = pp.lag[j], lagF = pp.lag[nw];
     const int NBs = (Lp + sw.maxw + STP_B - 1) / STP_B;        // blocks until every stage has emitted every position
     const int NIT = NBs + lagF + 1;
-    float xn[STP_B];
+    float xn[STP_B], xen[STP_B];                               // next block's ingest / emit samples
     auto fetch = [&](int b) {
         if (b >= 0 && b * STP_B + STP_B <= Lp) {               // whole block inside the line: no per-element test
             const float* xb = x + (size_t)(p0 + b * STP_B) * Cs;
@@ -203,23 +210,31 @@ k_colst_pipe(const float* __restrict__ data, const double* __restrict__ med, uin
                 xn[u] = (b >= 0 && i < Lp) ? x[(size_t)(p0 + i) * Cs] : 0.0f;
             }
         }
+        const int e0 = b * STP_B + 1 - w;                      // the samples leaving the window: w - 1 rows back
+        if (b >= 0 && e0 >= 0 && e0 + STP_B <= Lp) {
+            const float* xb = x + (size_t)(p0 + e0) * Cs;
+#pragma unroll
+            for (int u = 0; u < STP_B; u++) xen[u] = xb[(size_t)u * Cs];
+        } else {
+#pragma unroll
+            for (int u = 0; u < STP_B; u++) {
+                const int e = e0 + u;
+                xen[u] = (b >= 0 && e >= 0 && e < Lp) ? x[(size_t)(p0 + e) * Cs] : 0.0f;
+            }
+        }
     };
     // One block of 16 steps with every LDS read first and every LDS write last (windows of at least a block:
-    // nothing the block reads was written in it -- the prefix read at step u was written w >= 16 steps ago, a
-    // stage never sees its own flags).  ING / EMIT: every step of the block ingests / emits (uniform per block),
-    // so the 16 steps are straight-line code.
-    auto run_block = [&](const float (&xc)[STP_B], auto ing_tag, auto emit_tag) {
+    // nothing the block reads was written in it -- a stage never sees its own flags).  ING / EMIT: every step
+    // of the block ingests / emits (uniform per block), so the 16 steps are straight-line code.
+    auto run_block = [&](const float (&xc)[STP_B], const float (&xe)[STP_B], auto ing_tag, auto emit_tag) {
         constexpr bool ING = decltype(ing_tag)::value, EMIT = decltype(emit_tag)::value;
         uint8_t ain[STP_B], aem[STP_B];
-        double rold[STP_B], cumv[STP_B];
-        int sl[STP_B], em[STP_B];
+        int em[STP_B];
 #pragma unroll
         for (int u = 0; u < STP_B; u++) {
-            sl[u] = slot; em[u] = aemit;
+            em[u] = aemit;
             if (ING) ain[u] = acc[(size_t)(apos + u) * 64];    // (accn is a multiple of 16: no wrap inside the block)
-            if (ING && EMIT) rold[u] = ring[(size_t)slot * 64];
             if (EMIT) aem[u] = acc[(size_t)aemit * 64];
-            slot = slot + 1 == w ? 0 : slot + 1;
             aemit = aemit + 1 == accn ? 0 : aemit + 1;
         }
         apos = apos + STP_B == accn ? 0 : apos + STP_B;
@@ -234,11 +249,17 @@ k_colst_pipe(const float* __restrict__ data, const double* __restrict__ med, uin
                 clamped = cp ? limit : (cn ? -limit : clamped);
                 const double cumnew = cumlast + clamped;
                 cumlast = cumnew;
-                cumv[u] = cumnew;
                 if (EMIT) {
-                    const double S = cumnew - rold[u];
+                    const double S = cumnew - cumlag;          // cum[i + 1] - cum[e]
                     hp = S * scale > limit;
                     hn = S * (-scale) > limit;
+                    // c_e again, from the byte the stage saw when it ingested x_e (aem[u] before this stage's own bits)
+                    const uint8_t ae = aem[u];
+                    double ce = (double)xe[u];
+                    const bool ep = (ae & 1) && ce > limit;
+                    const bool en = !ep && (ae & 2) && ce < -limit;
+                    ce = ep ? limit : (en ? -limit : ce);
+                    cumlag = cumlag + ce;                      // cum[e + 1]
                 }
             }
             if (EMIT) {
@@ -250,7 +271,6 @@ k_colst_pipe(const float* __restrict__ data, const double* __restrict__ med, uin
         }
 #pragma unroll
         for (int u = 0; u < STP_B; u++) {
-            if (ING) ring[(size_t)sl[u] * 64] = cumv[u];
             if (EMIT) acc[(size_t)em[u] * 64] = aem[u];
         }
     };
@@ -258,19 +278,19 @@ k_colst_pipe(const float* __restrict__ data, const double* __restrict__ med, uin
     __syncthreads();
     for (int it = 0; it < NIT; it++) {
         const int b = it - lag;                                // this stage's block
-        float xc[STP_B];
+        float xc[STP_B], xe[STP_B];
 #pragma unroll
-        for (int u = 0; u < STP_B; u++) xc[u] = xn[u];
+        for (int u = 0; u < STP_B; u++) { xc[u] = xn[u]; xe[u] = xen[u]; }
         fetch(b + 1);
         const int i0 = b * STP_B, e0 = i0 + 1 - w;             // first ingest / emit position of the block
         const bool all_in = i0 + STP_B <= Lp, none_in = i0 >= Lp;
         const bool all_em = e0 >= 0 && e0 + STP_B <= Lp, none_em = e0 + STP_B <= 0;
         if (b >= 0 && b < NBs && w >= STP_B && all_in && all_em) {
-            run_block(xc, std::true_type{}, std::true_type{});
+            run_block(xc, xe, std::true_type{}, std::true_type{});
         } else if (b >= 0 && b < NBs && w >= STP_B && all_in && none_em) {
-            run_block(xc, std::true_type{}, std::false_type{});
+            run_block(xc, xe, std::true_type{}, std::false_type{});
         } else if (b >= 0 && b < NBs && w >= STP_B && none_in && all_em) {
-            run_block(xc, std::false_type{}, std::true_type{});
+            run_block(xc, xe, std::false_type{}, std::true_type{});
         } else if (b >= 0 && b < NBs) {
 #pragma unroll
             for (int u = 0; u < STP_B; u++) {
@@ -286,11 +306,15 @@ k_colst_pipe(const float* __restrict__ data, const double* __restrict__ med, uin
                         const double cumnew = cumlast + clamped;
                         cumlast = cumnew;
                         if (e >= 0) {
-                            const double S = cumnew - ring[(size_t)slot * 64];
+                            const double S = cumnew - cumlag;
                             hp = S * scale > limit;
                             hn = S * (-scale) > limit;
+                            const uint8_t ae = acc[(size_t)aemit * 64];     // (before this stage's own bits go in below)
+                            double ce = (double)xe[u];
+                            if ((ae & 1) && ce > limit) ce = limit;
+                            else if ((ae & 2) && ce < -limit) ce = -limit;
+                            cumlag = cumlag + ce;
                         }
-                        ring[(size_t)slot * 64] = cumnew;
                     }
                     if (e >= 0) {
                         sincep = hp ? 0 : min(sincep + 1, 1 << 30);
@@ -299,7 +323,6 @@ k_colst_pipe(const float* __restrict__ data, const double* __restrict__ med, uin
                         if (add) acc[(size_t)aemit * 64] |= add;
                     }
                 }
-                slot = slot + 1 == w ? 0 : slot + 1;
                 apos = apos + 1 == accn ? 0 : apos + 1;
                 aemit = aemit + 1 == accn ? 0 : aemit + 1;
             }

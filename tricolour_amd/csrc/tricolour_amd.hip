@@ -755,7 +755,7 @@ int launch_colfilter(const Run& r, int srcmode, float* bufW, float* bufO, const 
     return TRI_OK;
 }
 
-// K7p applies: up to eight windows whose float64 prefix rings (+ the flag ring) fit the CU's LDS
+// K7p applies: up to eight windows whose flag-byte ring fits the CU's LDS (there are no prefix rings any more)
 // (TRI_ST_NO_PIPE=1 keeps the global-scratch kernel)
 bool st_use_pipe(const StWin& sw) {
     static const bool off = [] { const char* e = getenv("TRI_ST_NO_PIPE"); return e && e[0] == '1'; }();
@@ -779,7 +779,7 @@ int launch_colst(const Run& r, const StWin& sw, const float* data, const double*
             hipLaunchKernelGGL((k_colst_fused<1, 2, 4, 8>), grid, dim3(blk), 0, r.st, data, med, out,
                                d_chunk_ends, fa, thr_scale, L, C, G, ws_data, ws_out);
     } else if (st_use_pipe(sw)) {
-        // any window list whose prefix rings fit LDS: one window per wave (K7p)
+        // any list of up to eight windows: one window per wave, lagging twin accumulators (K7p)
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colst_pipe),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         HIPCHK(attr);
@@ -1740,7 +1740,7 @@ extern "C" int tri_bench_sumthreshold(const float* data, const double* mad, uint
         return set_err(TRI_EUNSUPPORTED, "lane-mask cascade needs a window below 2^31 bytes");
     if (variant == 0 && can_fuse) variant = st_use_mask(L, C) ? 3 : 2;
     if (variant == 4) {
-        if (sw.nw > 8 || stp_lds_bytes(sw) > 160 * 1024) return set_err(TRI_EUNSUPPORTED, "stage pipeline: the prefix rings do not fit LDS");
+        if (sw.nw > 8 || stp_lds_bytes(sw) > 160 * 1024) return set_err(TRI_EUNSUPPORTED, "stage pipeline: more than eight windows, or the flag ring does not fit LDS");
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colst_pipe), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     bool fused = variant == 2;
