@@ -156,7 +156,7 @@ __host__ inline size_t stp_lds_bytes(const StWin& sw) {
 }
 
 #ifndef STP_MINWAVES
-#define STP_MINWAVES 1                  // (tuning: minimum waves per SIMD the register allocation must allow)
+#define STP_MINWAVES 3                  // (tuning: minimum waves per SIMD the register allocation must allow; 1: 49.5 ms, 3: 41.7 ms, 4 spills: 103 ms per 880-window pass)
 #endif
 __global__ void __launch_bounds__(512, STP_MINWAVES)
 k_colst_pipe(const float* __restrict__ data, const double* __restrict__ med, uint8_t* __restrict__ out,
@@ -238,40 +238,57 @@ k_colst_pipe(const float* __restrict__ data, const double* __restrict__ med, uin
             aemit = aemit + 1 == accn ? 0 : aemit + 1;
         }
         apos = apos + STP_B == accn ? 0 : apos + STP_B;
+        // Flags of earlier windows are sparse: when no line of the wave carries one anywhere in the block (neither at
+        // the ingest nor at the emit positions) the clamps are the identity and the 16 steps are adds and compares only.
+        unsigned any = 0;
 #pragma unroll
-        for (int u = 0; u < STP_B; u++) {
-            bool hp = false, hn = false;
-            if (ING) {
-                const uint8_t a = ain[u];
-                double clamped = (double)xc[u];
-                const bool cp = (a & 1) && clamped > limit;
-                const bool cn = !cp && (a & 2) && clamped < -limit;
-                clamped = cp ? limit : (cn ? -limit : clamped);
-                const double cumnew = cumlast + clamped;
-                cumlast = cumnew;
+        for (int u = 0; u < STP_B; u++) any |= (ING ? (unsigned)ain[u] : 0u) | (EMIT ? (unsigned)aem[u] : 0u);
+        unsigned fresh = 0;                                     // bits this block adds
+        auto steps = [&](auto clamp_tag) {
+            constexpr bool CLAMP = decltype(clamp_tag)::value;
+#pragma unroll
+            for (int u = 0; u < STP_B; u++) {
+                bool hp = false, hn = false;
+                if (ING) {
+                    double clamped = (double)xc[u];
+                    if (CLAMP) {
+                        const uint8_t a = ain[u];
+                        const bool cp = (a & 1) && clamped > limit;
+                        const bool cn = !cp && (a & 2) && clamped < -limit;
+                        clamped = cp ? limit : (cn ? -limit : clamped);
+                    }
+                    const double cumnew = cumlast + clamped;
+                    cumlast = cumnew;
+                    if (EMIT) {
+                        const double S = cumnew - cumlag;      // cum[i + 1] - cum[e]
+                        hp = S * scale > limit;
+                        hn = S * (-scale) > limit;
+                        // c_e again, from the byte the stage saw when it ingested x_e (aem[u] before this stage's own bits)
+                        double ce = (double)xe[u];
+                        if (CLAMP) {
+                            const uint8_t ae = aem[u];
+                            const bool ep = (ae & 1) && ce > limit;
+                            const bool en = !ep && (ae & 2) && ce < -limit;
+                            ce = ep ? limit : (en ? -limit : ce);
+                        }
+                        cumlag = cumlag + ce;                  // cum[e + 1]
+                    }
+                }
                 if (EMIT) {
-                    const double S = cumnew - cumlag;          // cum[i + 1] - cum[e]
-                    hp = S * scale > limit;
-                    hn = S * (-scale) > limit;
-                    // c_e again, from the byte the stage saw when it ingested x_e (aem[u] before this stage's own bits)
-                    const uint8_t ae = aem[u];
-                    double ce = (double)xe[u];
-                    const bool ep = (ae & 1) && ce > limit;
-                    const bool en = !ep && (ae & 2) && ce < -limit;
-                    ce = ep ? limit : (en ? -limit : ce);
-                    cumlag = cumlag + ce;                      // cum[e + 1]
+                    // (counters start at 2^30 and a line has far fewer than 2^30 positions: no saturation needed here)
+                    sincep = hp ? 0 : sincep + 1;
+                    sincen = hn ? 0 : sincen + 1;
+                    const unsigned add = (sincep < w ? 1u : 0u) | (sincen < w ? 2u : 0u);
+                    fresh |= add;
+                    aem[u] |= (uint8_t)add;
                 }
             }
-            if (EMIT) {
-                // (counters start at 2^30 and a line has far fewer than 2^30 positions: no saturation needed here)
-                sincep = hp ? 0 : sincep + 1;
-                sincen = hn ? 0 : sincen + 1;
-                aem[u] |= (uint8_t)((sincep < w ? 1 : 0) | (sincen < w ? 2 : 0));
-            }
-        }
+        };
+        if (__builtin_amdgcn_ballot_w64(any != 0) == 0) steps(std::false_type{});
+        else steps(std::true_type{});
+        if (EMIT && __builtin_amdgcn_ballot_w64(fresh != 0) != 0) {      // (nothing new anywhere in the wave: bytes unchanged)
 #pragma unroll
-        for (int u = 0; u < STP_B; u++) {
-            if (EMIT) acc[(size_t)em[u] * 64] = aem[u];
+            for (int u = 0; u < STP_B; u++) acc[(size_t)em[u] * 64] = aem[u];
         }
     };
     fetch(-lag);                                               // (this wave's block 0 comes `lag` iterations in)
