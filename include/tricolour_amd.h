@@ -287,11 +287,22 @@ int tri_bench_sumthreshold(const float *data, const double *mad, uint8_t *out,
  * For stage 2: 0 = default route, 1 = register delay lines (K4r), 2 / 3 = the
  * stage pipeline across four waves (K4p) with blocks of 16 / 8 positions
  * (TRI_EUNSUPPORTED when that block length does not apply to the shape).
+ * For stage 1 also: 3 = the eight-wave stage pipeline (K4qf), 4 = the exact
+ * row filter (K4x: one line pair resident in LDS, lanes = positions, any
+ * radius; the time covers the kernel and the transpose of its rows to out_o).
  */
 int tri_bench_boxfilter(const float *data, const uint8_t *flags4, float *out_w,
                         float *out_o, int64_t n_win, int64_t n_line, int64_t n_col,
                         int64_t radius, int stage, int variant, int repeats,
                         float *ms_per_launch, void *stream);
+
+/*
+ * Test hook: how many line passes the last tri_bench_boxfilter(stage 1,
+ * variant 4) call of this thread ran, and how many of them failed the exactness
+ * check and were redone in the reference's sequential order
+ * (kernels_boxexact.hpp; flagging.py:398-416).
+ */
+int tri_boxx_last_stats(uint64_t *passes, uint64_t *sequential);
 
 /*
  * Test hook: tri_sum_threshold_flagger that additionally taps the LAST major

@@ -223,6 +223,65 @@ def test_frequency_stage_routes(gpu, shape, radius):
         assert ok.all(), "variant %d: %d of %d words differ (first at %s)" % (variant, (~ok).sum(), ok.size, np.argwhere(~ok)[0])
 
 
+def _freq_stage_expected(oracle, wimg, oimg, data, radius):
+    """flagging.py:362-419 row by row on both images, :506-513 masked division, :563-566 |data - background|,
+    evaluated with the oracle's sequential box filter (any radius)."""
+    w, t, f = wimg.shape
+    out = np.empty((w, f, t), np.float32)
+    with np.errstate(all="ignore"):
+        for k in range(w):
+            fw = np.stack([oracle.box_gaussian_filter1d(wimg[k, i], radius, 4) for i in range(t)])
+            fo = np.stack([oracle.box_gaussian_filter1d(oimg[k, i], radius, 4) for i in range(t)])
+            bg = np.where(fw == 0, np.float32(np.nan), fo / fw).astype(np.float32)
+            out[k] = np.abs(data[k] - bg.T)
+    return out
+
+
+def _boxx_stats():
+    import ctypes as C
+    from tricolour_amd import _lib
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    _lib.check(_lib.lib().tri_boxx_last_stats(C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
+@pytest.mark.parametrize("shape,radius", [((1, 24, 4096), 277), ((1, 12, 4096), 221), ((1, 12, 4096), 166), ((1, 16, 4096), 110),
+                                          ((2, 20, 4096), 43), ((1, 16, 1024), 17), ((1, 12, 256), 8), ((1, 12, 512), 166),
+                                          ((1, 8, 64), 30), ((1, 8, 5376), 55)])
+def test_exact_row_filter_vs_oracle(gpu, oracle, shape, radius):
+    """K4x (kernels_boxexact.hpp): lanes = positions of one LDS-resident line, exactness of the float64 sums checked
+    per pass, sequential redo otherwise.  Bit for bit against the oracle's sequential filter for (a) ordinary images
+    (no line may need the redo), (b) images whose dynamic range breaks exactness, negative / infinite / NaN terms."""
+    w, t, f = shape
+    rs = np.random.RandomState(radius * 7 + f)
+    wimg = (rs.uniform(size=shape) * 0.45 + 0.5).astype(np.float32)
+    wimg[:, :, f // 3: f // 3 + min(5 * radius, f // 4)] = 0.0     # fully flagged band -> NaN background when wider than the filter
+    wimg[:, 1, :] = 0.0                                            # a line without any weight
+    oimg = (wimg * (rs.uniform(size=shape) * 10 + 5)).astype(np.float32)   # (positive, a few bits of dynamic range: amplitudes)
+    data = (rs.standard_normal((w, f, t)) * 3 + 10).astype(np.float32)
+    exp = _freq_stage_expected(oracle, wimg, oimg, data, radius)
+    got = _freq_stage(wimg, oimg, data, radius, 4)
+    ok = _same_f32(exp, got)
+    assert ok.all(), "ordinary images: %d of %d words differ (first at %s)" % ((~ok).sum(), ok.size, np.argwhere(~ok)[0])
+    passes, seq = _boxx_stats()
+    assert passes == 4 * 2 * w * t and seq == 0, (passes, seq)
+    # (b) hostile lines
+    o2 = oimg.copy()
+    o2[:, 2, :] *= (10.0 ** rs.uniform(-15, 15, size=f)).astype(np.float32)       # 2^100 of dynamic range: sums inexact
+    o2[:, 3, f // 2] = -3.0                                                        # a negative term
+    o2[:, 4, f // 5] = np.inf
+    o2[:, 5, 2 * f // 3] = np.nan
+    o2[:, 0, :4] = np.float32(1e-30)                                               # tiny terms at the line's start only
+    w2 = wimg.copy()
+    w2[:, 2, ::7] = np.float32(1e-12)
+    exp = _freq_stage_expected(oracle, w2, o2, data, radius)
+    got = _freq_stage(w2, o2, data, radius, 4)
+    ok = _same_f32(exp, got)
+    assert ok.all(), "hostile images: %d of %d words differ (first at %s)" % ((~ok).sum(), ok.size, np.argwhere(~ok)[0])
+    passes, seq = _boxx_stats()
+    assert passes == 4 * 2 * w * t and 0 < seq <= 4 * 2 * w * 6, (passes, seq)
+
+
 def test_random_windows_multi_batch(gpu, oracle):
     """Several windows, tiny workspace budget -> several internal batches."""
     import os

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("TRICOLOUR_AMD_LIB") or os.path.join(_HERE, "libtricol
 SOURCES = [os.path.join(_HERE, "csrc", "tricolour_amd.hip")]   # one translation unit
 DEPENDS = [os.path.join(_HERE, "csrc", f) for f in (
     "tri_common.hpp", "kernels_elementwise.hpp", "kernels_median.hpp", "kernels_boxfilter.hpp", "kernels_boxline.hpp", "kernels_boxpipe.hpp",
+    "kernels_boxexact.hpp",
     "kernels_sumthreshold.hpp")]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "tricolour_amd.h")
 
@@ -129,6 +130,7 @@ _SIGNATURES = {
     "tri_bench_boxfilter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                       C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(C.c_float), C.c_void_p]),
+    "tri_boxx_last_stats": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "tri_test_box_divide": (C.c_int, [C.c_int64, C.POINTER(C.c_uint64), C.c_void_p]),
     "tri_test_median": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                   C.c_int64, C.POINTER(C.c_int64), C.c_int64, C.c_int, C.c_void_p]),

@@ -419,7 +419,13 @@ k_boxq(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags, 
 // Host: n % 4 == 0, ld % 4 == 0, img_gap % 4 == 0, 16-byte aligned images, windows below 2^31 bytes.
 // ---------------------------------------------------------------------------
 // LDS bytes for blocks of B positions: 144 KB at B = 16 (one workgroup per CU), 72 KB at B = 8 (two)
-__host__ __device__ constexpr size_t boxqf_lds_bytes(int B) { return (size_t)(2 * 4 * 4 * B * 64 + 2 * 2 * B * 64) * 4; }
+// Row pitch of the LDS tiles in floats.  The stage arithmetic reads / writes whole rows (lane = line: any pitch is
+// conflict-free); the transposing stage-in writes 4 (2) consecutive ROWS per thread with 4 threads per line, so with
+// a pitch of 64 the four threads of a line hit one bank.  A pitch = 2 (mod 8) spreads them: bank = 8 q + line (mod 32).
+#ifndef BOXQF_LW
+#define BOXQF_LW 64
+#endif
+__host__ __device__ constexpr size_t boxqf_lds_bytes(int B) { return (size_t)(2 * 4 * 4 * B * BOXQF_LW + 2 * 2 * B * BOXQF_LW) * 4; }
 #define BOXQF_LDS_BYTES boxqf_lds_bytes(16)
 // B = 8: half the FIFO memory and, for delay lines of up to 48 registers, half the register budget: TWO workgroups
 // (four waves per SIMD) share a compute unit -- twice the barriers per position against twice the latency hiding.
@@ -431,16 +437,17 @@ k_boxqf(const float* __restrict__ srcW, unsigned img_gap, float* __restrict__ ds
     constexpr int PP = B / 4;                                  // positions per thread when staging (4 or 2)
     constexpr int FN = B / 8;                                  // (position, line) pairs per thread when finishing (2 or 1)
     constexpr int NBLK = KS / B;
-    constexpr int P = B == 8 ? (NBLK == 6 ? 3 : NBLK) : boxq_prefetch(KS);   // (B = 8: KS = 32, 40, 48 -> 4, 5, 3 blocks ahead: 128 registers)
+    constexpr int P = B == 8 ? (NBLK == 6 ? 3 : (NBLK == 8 ? 4 : NBLK)) : boxq_prefetch(KS);   // (B = 8: KS = 32, 40, 48, 56, 64 -> 4, 5, 3, 7, 4 blocks ahead: 128 registers)
     static_assert(KS % B == 0, "register part: whole blocks");
     static_assert(B == 8 || B == 16, "block length");
     constexpr int U = boxq_lcm(NBLK, P);
     constexpr unsigned OOB = 0x7ffffff0u;
     extern __shared__ float cf_ring[];
-    typedef float FifoT[4 * B][64];                            // one stage's input stream: 3 blocks + mirror of the first
-    typedef float OutT[B][64];
+    constexpr int LW = BOXQF_LW;
+    typedef float FifoT[4 * B][LW];                            // one stage's input stream: 3 blocks + mirror of the first
+    typedef float OutT[B][LW];
     FifoT* fifo = reinterpret_cast<FifoT*>(cf_ring);           // [2 images][4 stages]
-    OutT* outb = reinterpret_cast<OutT*>(cf_ring + 2 * 4 * 4 * B * 64);   // [2 images][2 blocks]
+    OutT* outb = reinterpret_cast<OutT*>(cf_ring + 2 * 4 * 4 * B * LW);   // [2 images][2 blocks]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int img = wave >> 2, st = wave & 3;                  // this wave's image and stage
@@ -449,7 +456,7 @@ k_boxqf(const float* __restrict__ srcW, unsigned img_gap, float* __restrict__ ds
     const int R2 = 2 * r;
     const int d = R2 - KS;                                     // host: 0 <= d < 16
     const int NB = (n + 4 * r + B - 1) / B;
-    for (int k = tid; k < 2 * 4 * 4 * B * 64; k += 512) cf_ring[k] = 0.0f;
+    for (int k = tid; k < 2 * 4 * 4 * B * LW; k += 512) cf_ring[k] = 0.0f;
 
     // staging: thread -> image (tid >> 8), line (tid & 255) / 4, positions PP (tid & 3) .. + PP - 1 of a block
     const int s_line = (tid & 255) >> 2, s_q = tid & 3;
@@ -513,10 +520,10 @@ k_boxqf(const float* __restrict__ srcW, unsigned img_gap, float* __restrict__ ds
                 const bool ok = s_lok && p < n;                // beyond the line end / the last line: zero input
                 float* pf = &fifo[img * 4][lslot * B + PP * s_q][s_line];
 #pragma unroll
-                for (int k = 0; k < PP; k++) pf[k * 64] = ok ? pre[q][k] : 0.0f;
+                for (int k = 0; k < PP; k++) pf[k * LW] = ok ? pre[q][k] : 0.0f;
                 if (lslot == 0) {
 #pragma unroll
-                    for (int k = 0; k < PP; k++) pf[(3 * B + k) * 64] = ok ? pre[q][k] : 0.0f;
+                    for (int k = 0; k < PP; k++) pf[(3 * B + k) * LW] = ok ? pre[q][k] : 0.0f;
                 }
                 lslot = lslot == 2 ? 0 : lslot + 1;
             }
@@ -528,7 +535,7 @@ k_boxqf(const float* __restrict__ srcW, unsigned img_gap, float* __restrict__ ds
                 const float* pd = &fifo[wave][s0][lane];
                 float xin[B], xdel[B], o[B];
 #pragma unroll
-                for (int u = 0; u < B; u++) { xin[u] = pi[u * 64]; xdel[u] = pd[u * 64]; }
+                for (int u = 0; u < B; u++) { xin[u] = pi[u * LW]; xdel[u] = pd[u * LW]; }
 #pragma unroll
                 for (int u = 0; u < B; u++) {
                     const float old = R[sb + u];
@@ -540,23 +547,23 @@ k_boxqf(const float* __restrict__ srcW, unsigned img_gap, float* __restrict__ ds
                 if (st == 3) {
                     float* ob = &outb[img * 2 + (b & 1)][0][lane];
 #pragma unroll
-                    for (int u = 0; u < B; u++) ob[u * 64] = o[u];
+                    for (int u = 0; u < B; u++) ob[u * LW] = o[u];
                 } else {
                     const bool whole = t0 >= keep_lo && t0 + B <= keep_hi && b >= 0;
                     float* po = &fifo[wave + 1][slot * B][lane];
                     if (whole) {
 #pragma unroll
-                        for (int u = 0; u < B; u++) po[u * 64] = o[u];
+                        for (int u = 0; u < B; u++) po[u * LW] = o[u];
                     } else {
 #pragma unroll
                         for (int u = 0; u < B; u++) {
                             o[u] = (t0 + u >= keep_lo && t0 + u < keep_hi) ? o[u] : 0.0f;
-                            po[u * 64] = o[u];
+                            po[u * LW] = o[u];
                         }
                     }
                     if (slot == 0) {
 #pragma unroll
-                        for (int u = 0; u < B; u++) po[(3 * B + u) * 64] = o[u];
+                        for (int u = 0; u < B; u++) po[(3 * B + u) * LW] = o[u];
                     }
                 }
                 slot = slot == 2 ? 0 : slot + 1;

@@ -11,6 +11,7 @@
 #include "kernels_boxfilter.hpp"
 #include "kernels_boxline.hpp"
 #include "kernels_boxpipe.hpp"
+#include "kernels_boxexact.hpp"
 #include "kernels_sumthreshold.hpp"
 
 // ===========================================================================
@@ -353,6 +354,10 @@ struct Run {
     // NaNs folded into the running flags; the time-axis filter masks by its own flags),
     // ws.dataFT their transpose, masked in place every iteration (the flags only grow)
     bool ampl_cached = false;
+    // the iteration's input flags in TF layout while ws.dataTF is unmasked (K4x masks its data row with them:
+    // data is zero where the iteration's _average_freq flagged it, flagging.py:858-870), else NULL
+    const uint8_t* data_mask = nullptr;
+    size_t data_mask_ws = 0;
 };
 
 // The register cascade covers windows exactly (1,2,4,8) in that order; the
@@ -966,6 +971,9 @@ extern thread_local int g_boxq_override;
 #ifndef BOXQF_B8_DEFAULT
 #define BOXQF_B8_DEFAULT 1
 #endif
+#ifndef BOXQF_B8_MAX2R
+#define BOXQF_B8_MAX2R 56                // blocks of 8 positions below this delay (56: up to 48 registers; 72: up to 64)
+#endif
 template <int KS, int MODE, int B = 16>
 int launch_boxqf_ks(const Run& r, const float* srcW, unsigned gap, float* dstW, float* dstO, const float* data,
                     int n, int C, int ld, int rad, size_t sws_img, size_t dws, size_t ws_data, int64_t W, uint8_t* nanflag) {
@@ -993,11 +1001,15 @@ int launch_boxf(const Run& r, int ks, const float* srcW, const float* srcO, floa
             const unsigned gap = (unsigned)(srcO - srcW);
             // blocks of 8 positions (two workgroups per CU) while the delay line leaves the registers for it
             static const int b8 = [] { const char* e = getenv("TRI_FILTER_PIPE_F_B8"); return e ? atoi(e) : BOXQF_B8_DEFAULT; }();
-            if (b8 && 2 * rad >= 32 && 2 * rad < 56) {
+            if (b8 && 2 * rad >= 32 && 2 * rad < BOXQF_B8_MAX2R) {
                 switch (2 * rad / 8 * 8) {
                     case 32: return launch_boxqf_ks<32, MODE, 8>(r, srcW, gap, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
                     case 40: return launch_boxqf_ks<40, MODE, 8>(r, srcW, gap, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
                     case 48: return launch_boxqf_ks<48, MODE, 8>(r, srcW, gap, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
+#if BOXQF_B8_MAX2R > 56
+                    case 56: return launch_boxqf_ks<56, MODE, 8>(r, srcW, gap, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
+                    case 64: return launch_boxqf_ks<64, MODE, 8>(r, srcW, gap, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
+#endif
                 }
             }
             switch (kq) {
@@ -1018,6 +1030,71 @@ int launch_boxf(const Run& r, int ks, const float* srcW, const float* srcO, floa
         case 80: return launch_boxf_ks<80, MODE>(r, srcW, srcO, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
     }
     return set_err(TRI_EINVAL, "no register-ring kernel for %d slots", ks);
+}
+
+// K4x: the frequency-axis stage + masked division for any radius, one line pair resident in LDS, lanes =
+// positions, exactness checked per pass with a sequential redo (kernels_boxexact.hpp).  Rows in, rows out.
+// The flagger takes it where no stage pipeline exists (r >= 56: final_st_very_broad's 277 / 221 / 166 / 110);
+// TRI_FILTER_NO_EXACT=1 restores the lane-per-stage / in-place multi-pass routes (A/B runs, tests).
+thread_local int g_boxx_override = -1;   // tests / benches: 0 = off, 1 = on wherever the shape allows
+thread_local unsigned long long g_boxx_last_stats[2] = {0, 0};
+#ifndef BOXX_MIN_R
+#define BOXX_MIN_R 56
+#endif
+int boxx_pick_l(int rad, int n) {
+    static const bool env_off = [] { const char* e = getenv("TRI_FILTER_NO_EXACT"); return e && e[0] == '1'; }();
+    if (g_boxx_override == 0 || (g_boxx_override < 0 && (env_off || rad < BOXX_MIN_R))) return 0;
+    if (rad < 1 || n % 4 != 0) return 0;
+    const int64_t P = (int64_t)n + 4 * (int64_t)rad;
+    for (int L : {17, 19, 21, 25}) {
+        if (256 * (int64_t)L < P || L > 2 * rad + 1 || (2 * rad + 1) / L > BOXX_AMAX) continue;
+        if (boxx_lds_bytes(L, rad) > 159 * 1024) continue;
+        return L;
+    }
+    return 0;
+}
+// the reciprocal division is verified exhaustively for these radii only (test_division_by_box_denominator)
+static bool boxx_recip_ok(int rad) { return rad <= 128 || rad == 166 || rad == 221 || rad == 277 || rad == 397 || rad == 795; }
+
+template <int L, int MODE>
+int launch_boxx_l(const Run& r, const float* srcW, unsigned gap, const float* data, const uint8_t* mask, float* outA, float* outB,
+                  int n, int C, int ld, int rad, size_t sws_img, size_t ws_data, size_t ws_mask, size_t ws_outA, size_t ws_outB,
+                  int64_t W, uint8_t* nanflag, unsigned long long* stats) {
+    const BoxDenom denom = box_reciprocal(box_denominator(rad));
+    const size_t lds = boxx_lds_bytes(L, rad);
+    dim3 grid((unsigned)C, (unsigned)W);
+    if (boxx_recip_ok(rad)) {
+        // (the kernel also has a few static LDS bytes -- __syncthreads_or -- so ask for what this launch needs, not for 160 KB)
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boxx<L, MODE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_boxx<L, MODE, true>), grid, dim3(512), lds, r.st, srcW, gap, data, mask, outA, outB, n, ld, rad, denom, sws_img,
+                           ws_data, ws_mask, ws_outA, ws_outB, nanflag, stats);
+    } else {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boxx<L, MODE, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_boxx<L, MODE, false>), grid, dim3(512), lds, r.st, srcW, gap, data, mask, outA, outB, n, ld, rad, denom, sws_img,
+                           ws_data, ws_mask, ws_outA, ws_outB, nanflag, stats);
+    }
+    LAUNCHCHK();
+    return TRI_OK;
+}
+// rows of (srcW, srcO) [C][ld] + data rows [C][n] (+ byte mask rows) -> outA (MODE 1: |data - bg|; MODE 2: bg), outB (MODE 2: data - bg),
+// rows [C][ld]; outputs may alias the inputs (a workgroup has its whole line in LDS before it writes)
+template <int MODE>
+int launch_boxx(const Run& r, int L, const float* srcW, const float* srcO, const float* data, const uint8_t* mask, float* outA, float* outB,
+                int n, int C, int ld, int rad, size_t sws_img, size_t ws_data, size_t ws_mask, size_t ws_outA, size_t ws_outB,
+                int64_t W, uint8_t* nanflag, unsigned long long* stats = nullptr) {
+    if (srcO <= srcW || ld % 4 != 0 || sws_img % 4 != 0 || (uint64_t)(srcO - srcW) % 4 != 0 || ((uintptr_t)srcW % 16 != 0) ||
+        ((uintptr_t)data % 16 != 0) || ws_data % 4 != 0 || ((uintptr_t)outA % 16 != 0) || ws_outA % 4 != 0 ||
+        (mask && (((uintptr_t)mask % 4 != 0) || ws_mask % 4 != 0)) || (uint64_t)(srcO - srcW) > 0xffffffffull ||
+        (MODE == 2 && (((uintptr_t)outB % 16 != 0) || ws_outB % 4 != 0)) || C > 65535 * 1024)
+        return set_err(TRI_EUNSUPPORTED, "exact row filter: unaligned images");
+    const unsigned gap = (unsigned)(srcO - srcW);
+    switch (L) {
+        case 17: return launch_boxx_l<17, MODE>(r, srcW, gap, data, mask, outA, outB, n, C, ld, rad, sws_img, ws_data, ws_mask, ws_outA, ws_outB, W, nanflag, stats);
+        case 19: return launch_boxx_l<19, MODE>(r, srcW, gap, data, mask, outA, outB, n, C, ld, rad, sws_img, ws_data, ws_mask, ws_outA, ws_outB, W, nanflag, stats);
+        case 21: return launch_boxx_l<21, MODE>(r, srcW, gap, data, mask, outA, outB, n, C, ld, rad, sws_img, ws_data, ws_mask, ws_outA, ws_outB, W, nanflag, stats);
+        case 25: return launch_boxx_l<25, MODE>(r, srcW, gap, data, mask, outA, outB, n, C, ld, rad, sws_img, ws_data, ws_mask, ws_outA, ws_outB, W, nanflag, stats);
+    }
+    return set_err(TRI_EINVAL, "no exact row filter for chunks of %d", L);
 }
 
 // Lane-per-stage variant of the same (radii 17..LANE4_R_MAX): k_colfilter_lane4<3, *>.
@@ -1151,8 +1228,10 @@ int background2d(const Run& r, bool flagsFT_current) {
         // frequency stage able to read the time stage's TF images itself (no transposes)
         // register-ring fused frequency stage (signed 32-bit buffer offsets: window below 2^31 bytes)
         const int ksf = ((uint64_t)N * 4u < (1ull << 31) && ((uint64_t)(ws.Ao - ws.Aw) + N) * 4u < (1ull << 31)) ? boxr_pick_ks_f(r1) : 0;
-        const bool tin4 = !ksf && !colfilter_t_usable(r1) && colfilter_t4_usable(r1);
-        const bool tin = ksf > 0 || colfilter_t_usable(r1) || tin4;
+        // exact row filter (K4x) where the stage pipelines end: rows of the time stage's TF images in, rows out
+        const int xl = (r1 > 0 && (!ksf || r1 >= BOXX_MIN_R) && (!r.ampl_cached || r.data_mask)) ? boxx_pick_l(r1, Fa) : 0;
+        const bool tin4 = !xl && !ksf && !colfilter_t_usable(r1) && colfilter_t4_usable(r1);
+        const bool tin = xl > 0 || ksf > 0 || colfilter_t_usable(r1) || tin4;
         float* den_t_ptr = tin ? nullptr : &den_t;
         // (for the in-place multi-pass kernel, used at large radii, building on
         //  the fly measured faster: 11.4 vs 16.8 ms per call at 128 windows)
@@ -1202,8 +1281,23 @@ int background2d(const Run& r, bool flagsFT_current) {
         //     in-place multi-pass filter, rows [0, Fa) for the single-sweep one ---
         size_t off = colfilter_lds_block(r1, T) > 0 ? 0 : (size_t)4 * r1 * T;
         // frequency stage + masked division in one kernel when the four-ring stage applies
-        const bool fused_div = tin && !tin4 && !direct_ft && (ksf > 0 || colfilter_tf_usable(r1));
-        if (fused_div) {
+        const bool fused_div = tin && !tin4 && !direct_ft && (xl > 0 || ksf > 0 || colfilter_tf_usable(r1));
+        if (xl > 0 && !direct_ft) {
+            // rows are filtered in place (Ao <- |data - bg| or bg, Aw <- data - bg), then taken to the FT layout
+            const uint8_t* mk = r.ampl_cached ? r.data_mask : nullptr;
+            if (final_pass) {
+                HIPCHK(hipMemsetAsync(ws.rowcnt, 0, (size_t)W * T, r.st));
+                rc = launch_boxx<2>(r, xl, ws.Aw, ws.Ao, ws.dataTF, mk, ws.Ao, ws.Aw, Fa, T, Fa, r1, wsA, N, r.data_mask_ws, wsA, wsA, W,
+                                    reinterpret_cast<uint8_t*>(ws.rowcnt));
+                if (rc) return rc;
+                rc = launch_transpose<float>(r, ws.Aw, ws.Bw, T, Fa, wsA, wsB, W);
+            } else {
+                rc = launch_boxx<1>(r, xl, ws.Aw, ws.Ao, ws.dataTF, mk, ws.Ao, nullptr, Fa, T, Fa, r1, wsA, N, r.data_mask_ws, wsA, 0, W, nullptr);
+            }
+            if (rc) return rc;
+            rc = launch_transpose<float>(r, ws.Ao, ws.Bo, T, Fa, wsA, wsB, W);
+            if (rc) return rc;
+        } else if (fused_div) {
             if (final_pass) {
                 HIPCHK(hipMemsetAsync(ws.rowcnt, 0, (size_t)W * T, r.st));
                 if (ksf) rc = launch_boxf<2>(r, ksf, ws.Aw, ws.Ao, ws.Bw, ws.Bo, ws.dataFT, Fa, T, Fa, r1, wsA, wsB, N, W, reinterpret_cast<uint8_t*>(ws.rowcnt));
@@ -1354,6 +1448,9 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
     LAUNCHCHK();
 
     // flagging.py:957-962  2-D background (FT layout, ws.Bo), then the residual
+    // (K4x masks rows of the unmasked TF amplitudes with the iteration's input flags: same layout when nothing is averaged)
+    r.data_mask = (r.ampl_cached && Fa == F) ? iter_flags : nullptr;
+    r.data_mask_ws = N;
     rc = background2d(r, ft_current);
     if (rc) return rc;
     if (tap && r.dbg) {
@@ -1781,7 +1878,7 @@ extern "C" int tri_bench_boxfilter(const float* data, const uint8_t* flags4, flo
     if (n_win <= 0 || n_line <= 0 || n_col <= 0 || repeats <= 0 || n_win > 65535 || radius <= 0 || (stage != 2 && n_line % 4 != 0))
         return set_err(TRI_EINVAL, "bad shape");
     if (stage < 0 || stage > 2) return set_err(TRI_EUNSUPPORTED, "stage must be 0, 1 or 2");
-    if (variant < 0 || variant > 3) return set_err(TRI_EINVAL, "variant must be 0 .. 3");
+    if (variant < 0 || variant > 4 || (variant == 4 && stage != 1)) return set_err(TRI_EINVAL, "variant must be 0 .. 3 (4: exact row filter, stage 1 only)");
     if (stage == 2 && n_win != 1) return set_err(TRI_EINVAL, "the spectrum stage takes one window");
     Run r;
     r.st = (hipStream_t)stream;
@@ -1797,9 +1894,31 @@ extern "C" int tri_bench_boxfilter(const float* data, const uint8_t* flags4, flo
     // stage 0: 0 = the flagger's route, 1 = LDS delay lines, 2 = register delay lines (K4r), 3 = stage pipeline (K4q)
     if (stage == 0 || stage == 1) { g_boxq_override = variant == 0 ? -1 : (variant == 3 ? 1 : 0); if (variant == 3) g_boxr_override = -1; }
     int rc = TRI_OK;
+    // stage 1, variant 4: K4x works on rows -- the amplitudes are taken to the TF layout once (untimed), the rows it
+    // writes go back to FT inside the timed loop (as in the flagger); out_w doubles as the row buffer.
+    // ms_per_launch then covers kernel + transpose; the counters in stats[] are printed with TRI_BOXX_STATS=1
+    float* x_data_tf = nullptr;
+    unsigned long long* x_stats = nullptr;
+    int xl = 0;
+    if (stage == 1 && variant == 4) {
+        g_boxx_override = 1;
+        xl = boxx_pick_l((int)radius, (int)n_col);
+        g_boxx_override = -1;
+        if (!xl) return set_err(TRI_EUNSUPPORTED, "no exact row filter for radius %d on lines of %d", (int)radius, (int)n_col);
+        HIPCHK(hipMalloc(&x_data_tf, (size_t)n_win * N * sizeof(float)));
+        HIPCHK(hipMalloc(&x_stats, 2 * sizeof(unsigned long long)));
+        HIPCHK(hipMemsetAsync(x_stats, 0, 2 * sizeof(unsigned long long), r.st));
+        rc = launch_transpose<float>(r, data, x_data_tf, (int)n_col, (int)n_line, N, N, n_win);
+        if (rc) return rc;
+    }
     HIPCHK(hipEventRecord(e0, r.st));
     for (int i = 0; i < repeats && rc == TRI_OK; i++) {
-        if (stage == 2) {
+        if (xl) {
+            const float* srcW = reinterpret_cast<const float*>(flags4);
+            rc = launch_boxx<1>(r, xl, srcW, srcW + N, x_data_tf, nullptr, out_w, nullptr, (int)n_col, (int)n_line, (int)n_col, (int)radius,
+                                2 * N, N, 0, N, 0, n_win, nullptr, x_stats);
+            if (rc == TRI_OK) rc = launch_transpose<float>(r, out_w, out_o, (int)n_line, (int)n_col, N, N, n_win);
+        } else if (stage == 2) {
             // spectrum path: byte flags [n_line][n_col] + data -> filtered weight and data images
             if (variant >= 2 && boxp_pick_block((int)radius, (int)n_col) == 0) rc = set_err(TRI_EUNSUPPORTED, "no stage pipeline for this shape");
             else rc = launch_colfilter(r, 0, out_w, out_o, data, flags4, out_w, out_o, (int)n_line, (int)n_col, (int)radius, 0, 0, 0, 1, nullptr, false, true);
@@ -1839,6 +1958,24 @@ extern "C" int tri_bench_boxfilter(const float* data, const uint8_t* flags4, flo
     *ms_per_launch = ms / repeats;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    if (xl) {
+        unsigned long long h[2] = {0, 0};
+        HIPCHK(hipMemcpy(h, x_stats, sizeof(h), hipMemcpyDeviceToHost));
+        g_boxx_last_stats[0] = h[0];
+        g_boxx_last_stats[1] = h[1];
+        if (const char* e = getenv("TRI_BOXX_STATS")) if (e[0] == '1')
+            fprintf(stderr, "k_boxx r=%d L=%d: %llu line passes, %llu redone sequentially\n", (int)radius, xl, h[0], h[1]);
+        (void)hipFree(x_data_tf);
+        (void)hipFree(x_stats);
+    }
+    return TRI_OK;
+}
+
+// Test hook: line passes run / redone sequentially by the last tri_bench_boxfilter(stage 1, variant 4) of this thread
+extern "C" int tri_boxx_last_stats(uint64_t* passes, uint64_t* sequential) {
+    if (!passes || !sequential) return set_err(TRI_EINVAL, "NULL pointer argument");
+    *passes = g_boxx_last_stats[0];
+    *sequential = g_boxx_last_stats[1];
     return TRI_OK;
 }
 
