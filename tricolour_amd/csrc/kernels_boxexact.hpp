@@ -20,7 +20,7 @@
 // of L consecutive positions [l L, (l + 1) L).  One pass = forward box sum of width 2r + 1 (Appendix B.1 of
 // all four passes are that, with zeros beyond the end):
 //   * the window sum at the chunk's first position comes from the chunk totals T_c of the previous pass's
-//     output (a = (2r + 1) / L whole chunks) plus the prefix Q of the chunk the window ends in;
+//     output (a = (2r + 1) / L whole chunks) plus the m = (2r + 1) - a L positions after them, read from LDS;
 //   * then the recurrence S_{i+1} = S_i + (x_{i+2r+1} - x_i) along the chunk: x_i from registers (the thread's
 //     own outputs of the previous pass), x_{i+2r+1} from LDS, one LDS read and one LDS write per position;
 //   * the condition is CHECKED per thread and pass: B = sum of the chunk totals its windows touch bounds every
@@ -47,12 +47,15 @@
 #define BOXX_TN (256 + BOXX_AMAX + 2)
 __host__ __device__ constexpr int boxx_pb(int L, int r) { return (256 * L + 2 * r + 2 + 3) / 4 * 4; }
 __host__ __device__ constexpr size_t boxx_lds_bytes(int L, int r) {
-    return (size_t)2 * boxx_pb(L, r) * 4 + (size_t)2 * BOXX_TN * 8 * 2 + (size_t)2 * BOXX_TN * 4;
+    return (size_t)2 * boxx_pb(L, r) * 4 + (size_t)2 * BOXX_TN * 8 + (size_t)2 * BOXX_TN * 4;
 }
 
 // statistics (optional, tests / profiles): [0] line passes run, [1] line passes redone sequentially
 template <int L, int MODE, bool RECIP>
-__global__ void __launch_bounds__(512, 2)
+#ifndef BOXX_MINWAVES
+#define BOXX_MINWAVES 4                  // 128 registers: two workgroups per compute unit
+#endif
+__global__ void __launch_bounds__(512, BOXX_MINWAVES)
 k_boxx(const float* __restrict__ srcW, unsigned img_gap, const float* __restrict__ data, const uint8_t* __restrict__ mask,
        float* __restrict__ outA, float* __restrict__ outB, int n, int ld, int r, BoxDenom denom, size_t sws_img,
        size_t ws_data, size_t ws_mask, size_t ws_outA, size_t ws_outB, uint8_t* __restrict__ nanflag,
@@ -68,14 +71,13 @@ k_boxx(const float* __restrict__ srcW, unsigned img_gap, const float* __restrict
     const int R2 = 2 * r;
     float* X = cf_ring + (size_t)img * PB;
     double* Ts = reinterpret_cast<double*>(cf_ring + 2 * (size_t)PB) + (size_t)img * BOXX_TN;
-    double* Qs = reinterpret_cast<double*>(cf_ring + 2 * (size_t)PB) + (size_t)(2 + img) * BOXX_TN;
-    unsigned* Ms = reinterpret_cast<unsigned*>(reinterpret_cast<double*>(cf_ring + 2 * (size_t)PB) + 4 * (size_t)BOXX_TN) + (size_t)img * BOXX_TN;
+    unsigned* Ms = reinterpret_cast<unsigned*>(reinterpret_cast<double*>(cf_ring + 2 * (size_t)PB) + 2 * (size_t)BOXX_TN) + (size_t)img * BOXX_TN;
 
     // ---- stage in: zero pads, the line at offset 4r (flagging.py:392-395) ----
     for (int k = l; k < PB; k += 256) {
         if (k < 4 * r || k >= P) X[k] = 0.0f;
     }
-    for (int k = 256 + l; k < BOXX_TN; k += 256) { Ts[k] = 0.0; Qs[k] = 0.0; Ms[k] = 0xFFFFFFFFu; }
+    for (int k = 256 + l; k < BOXX_TN; k += 256) { Ts[k] = 0.0; Ms[k] = 0xFFFFFFFFu; }
     {
         const float* src = srcW + win * sws_img + (size_t)(img ? img_gap : 0u) + (size_t)line * ld;
         for (int q = l; q < n / 4; q += 256) {
@@ -94,7 +96,7 @@ k_boxx(const float* __restrict__ srcW, unsigned img_gap, const float* __restrict
     bool bad;                                                  // a term that is negative, infinite or NaN
     // own chunk from LDS -> registers, totals, smallest non-zero term (as bits - 1: zero wraps to the maximum)
     auto rescan = [&]() {
-        double T = 0.0, Q = 0.0;
+        double T = 0.0;
         unsigned mn = 0xFFFFFFFFu, mx = 0u;
 #pragma unroll
         for (int k = 0; k < L; k++) {
@@ -104,10 +106,9 @@ k_boxx(const float* __restrict__ srcW, unsigned img_gap, const float* __restrict
             mx = max(mx, b);
             od[k] = (double)v;
             T += od[k];
-            if (k + 1 == m) Q = T;
         }
         bad = mx >= 0x7F800000u;
-        Ts[l] = T; Qs[l] = Q; Ms[l] = mn;
+        Ts[l] = T; Ms[l] = mn;
     };
     rescan();
     __syncthreads();
@@ -116,11 +117,32 @@ k_boxx(const float* __restrict__ srcW, unsigned img_gap, const float* __restrict
 #pragma unroll 1
     for (int pass = 0; pass < 4; pass++) {
         // ---- window sum at the chunk's first position, bound and quantum of everything this thread will add ----
-        double acc = m > 0 ? Qs[l + a] : 0.0;
-        for (int c = 0; c < a; c++) acc += Ts[l + c];
-        const double bound = acc + Ts[l + a] + Ts[l + a + 1];
+        // (groups of independent LDS reads: a serial read-add loop would expose the LDS latency every time;
+        //  entries past the window read a neutral slot: the end of the tables / the zero pad of the line)
+        double acc = 0.0;
         unsigned mw = 0xFFFFFFFFu;
-        for (int c = 0; c <= a + 1; c++) mw = min(mw, Ms[l + c]);
+        for (int c0 = 0; c0 < a + 2; c0 += 8) {
+            double tv[8];
+            unsigned mv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int c = c0 + u;
+                tv[u] = Ts[c < a ? l + c : BOXX_TN - 1];
+                mv[u] = Ms[c < a + 2 ? l + c : BOXX_TN - 1];
+            }
+            acc += ((tv[0] + tv[1]) + (tv[2] + tv[3])) + ((tv[4] + tv[5]) + (tv[6] + tv[7]));
+            mw = min(mw, min(min(min(mv[0], mv[1]), min(mv[2], mv[3])), min(min(mv[4], mv[5]), min(mv[6], mv[7]))));
+        }
+        {
+            const int e0 = i0 + a * L;                         // the m positions after the whole chunks
+            for (int j0 = 0; j0 < m; j0 += 4) {
+                float xv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) xv[u] = X[j0 + u < m ? e0 + j0 + u : PB - 1];
+                acc += ((double)xv[0] + (double)xv[1]) + ((double)xv[2] + (double)xv[3]);
+            }
+        }
+        const double bound = acc + Ts[l + a] + Ts[l + a + 1];
         // exact if bound < 2^53 * 2^(e_m - 23): with biased exponent fields EB (float64, 1023) and Em (float32, 127, at
         // least 1: subnormals share the quantum 2^-149): (EB - 1023) + 1 <= 30 + (Em - 127), one more bit of slack for
         // the rounding of `bound` itself.  EB = 2047 (infinite / NaN totals) can never pass.
@@ -139,7 +161,7 @@ k_boxx(const float* __restrict__ srcW, unsigned img_gap, const float* __restrict
         float far[L];
 #pragma unroll
         for (int k = 0; k < L - 1; k++) far[k] = X[i0 + k + 1 + R2];
-        double T = 0.0, Q = 0.0;
+        double T = 0.0;
         unsigned mn = 0xFFFFFFFFu;
 #pragma unroll
         for (int k = 0; k < L; k++) {
@@ -148,7 +170,6 @@ k_boxx(const float* __restrict__ srcW, unsigned img_gap, const float* __restrict
             on[k] = ov;
             od[k] = (double)ov;                                // (a failed pass reloads od[] from the line: rescan())
             T += od[k];
-            if (k + 1 == m) { Q = T; asm volatile("" ::: "memory"); }   // (uniform branch, taken once: not a select per step)
             mn = min(mn, __float_as_uint(ov) - 1u);
         }
         // every far read of the workgroup is done before anybody overwrites the line; the same barrier tells
@@ -157,7 +178,7 @@ k_boxx(const float* __restrict__ srcW, unsigned img_gap, const float* __restrict
         if (!anyfail) {
 #pragma unroll
             for (int k = 0; k < L; k++) X[i0 + k] = on[k];
-            Ts[l] = T; Qs[l] = Q; Ms[l] = mn;
+            Ts[l] = T; Ms[l] = mn;
             bad = false;                                       // (finite, non-negative: float32 of an exact sum of such terms)
         } else {
             // the reference's own order, one thread per image, in place (flagging.py:398-416 with zeros added
