@@ -16,11 +16,12 @@
 //   does any other summation order.
 //
 // A workgroup holds one line of both images (weight, weight * data) in LDS, zero-padded as the reference pads it
-// (flagging.py:381-395: n + 4r positions, data at offset 4r).  512 threads: 256 per image, thread l owns the chunk
-// of L consecutive positions [l L, (l + 1) L).  One pass = forward box sum of width 2r + 1 (Appendix B.1 of
+// (flagging.py:381-395: n + 4r positions, data at offset 4r).  2 NTI threads: NTI (128 or 256) per image, thread l
+// owns the chunk of L consecutive positions [l L, (l + 1) L).  One pass = forward box sum of width 2r + 1 (Appendix B.1 of
 // all four passes are that, with zeros beyond the end):
 //   * the window sum at the chunk's first position comes from the chunk totals T_c of the previous pass's
-//     output (a = (2r + 1) / L whole chunks) plus the m = (2r + 1) - a L positions after them, read from LDS;
+//     output (a = (2r + 1) / L whole chunks) plus the m = (2r + 1) - a L positions after them, read from LDS
+//     (or a + 1 whole chunks minus the L - m positions too many, whichever is fewer);
 //   * then the recurrence S_{i+1} = S_i + (x_{i+2r+1} - x_i) along the chunk: x_i from registers (the thread's
 //     own outputs of the previous pass), x_{i+2r+1} from LDS, one LDS read and one LDS write per position;
 //   * the condition is CHECKED per thread and pass: B = sum of the chunk totals its windows touch bounds every
@@ -37,50 +38,60 @@
 // out = |data - bg| (rejection loop, :563-566), MODE 2: bg and data - bg + the line's NaN mark (:576-578, :962).
 // Lines are rows of the time stage's TF images and the outputs are rows too (written in place over the inputs by
 // the launcher; a transpose takes them to the FT layout the rest of the iteration expects).
-// grid (C lines, W windows), block 512, dynamic LDS boxx_lds_bytes(L, r).
-// Host: n % 4 == 0, n + 4r <= 256 L, L <= 2r + 1, (2r + 1) / L <= BOXX_AMAX, 16-byte aligned rows.
+// Long chunks (NTI = 128) spend fewer instructions per line: the per-thread cost of gathering a window's chunk
+// totals and minima falls with a = (2r + 1) / L, the recurrence costs the same per position either way.
+// grid (C lines, W windows), block 2 NTI, dynamic LDS boxx_lds_bytes(NTI, L, r).
+// Host: n % 4 == 0, n + 4r <= NTI L, L <= 2r + 1, (2r + 1) / L <= BOXX_AMAX, 16-byte aligned rows.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #define BOXX_AMAX 96
-#define BOXX_TN (256 + BOXX_AMAX + 2)
-__host__ __device__ constexpr int boxx_pb(int L, int r) { return (256 * L + 2 * r + 2 + 3) / 4 * 4; }
-__host__ __device__ constexpr size_t boxx_lds_bytes(int L, int r) {
-    return (size_t)2 * boxx_pb(L, r) * 4 + (size_t)2 * BOXX_TN * 8 + (size_t)2 * BOXX_TN * 4;
+__host__ __device__ constexpr int boxx_tn(int NTI) { return NTI + BOXX_AMAX + 2; }
+__host__ __device__ constexpr int boxx_pb(int NTI, int L, int r) { return (NTI * L + 2 * r + 2 + 3) / 4 * 4; }
+__host__ __device__ constexpr size_t boxx_lds_bytes(int NTI, int L, int r) {
+    return (size_t)2 * boxx_pb(NTI, L, r) * 4 + (size_t)2 * boxx_tn(NTI) * 8 + (size_t)2 * boxx_tn(NTI) * 4;
 }
 
 // statistics (optional, tests / profiles): [0] line passes run, [1] line passes redone sequentially
-template <int L, int MODE, bool RECIP>
 #ifndef BOXX_MINWAVES
-#define BOXX_MINWAVES 4                  // 128 registers: two workgroups per compute unit
+#define BOXX_MINWAVES 4                  // NTI = 256: 128 registers, two workgroups (16 waves) per compute unit
 #endif
-__global__ void __launch_bounds__(512, BOXX_MINWAVES)
+#ifndef BOXX_G
+#define BOXX_G 8
+#endif
+#ifndef BOXX_MINWAVES128
+#define BOXX_MINWAVES128 3               // NTI = 128: 168 registers, three workgroups (12 waves) per compute unit
+#endif
+template <int NTI, int L, int MODE, bool RECIP>
+__global__ void __launch_bounds__(2 * NTI, NTI == 256 ? BOXX_MINWAVES : BOXX_MINWAVES128)
 k_boxx(const float* __restrict__ srcW, unsigned img_gap, const float* __restrict__ data, const uint8_t* __restrict__ mask,
        float* __restrict__ outA, float* __restrict__ outB, int n, int ld, int r, BoxDenom denom, size_t sws_img,
        size_t ws_data, size_t ws_mask, size_t ws_outA, size_t ws_outB, uint8_t* __restrict__ nanflag,
        unsigned long long* __restrict__ stats) {
     extern __shared__ float cf_ring[];
     const int tid = threadIdx.x;
-    const int img = tid >> 8, l = tid & 255;
+    constexpr int TN = boxx_tn(NTI);
+    const int img = tid / NTI, l = tid % NTI;
     const int line = blockIdx.x;
     const size_t win = blockIdx.y;
     const int C = gridDim.x;
-    const int PB = boxx_pb(L, r);
+    const int PB = boxx_pb(NTI, L, r);
     const int P = n + 4 * r;
     const int R2 = 2 * r;
     float* X = cf_ring + (size_t)img * PB;
-    double* Ts = reinterpret_cast<double*>(cf_ring + 2 * (size_t)PB) + (size_t)img * BOXX_TN;
-    unsigned* Ms = reinterpret_cast<unsigned*>(reinterpret_cast<double*>(cf_ring + 2 * (size_t)PB) + 2 * (size_t)BOXX_TN) + (size_t)img * BOXX_TN;
+    double* Ts = reinterpret_cast<double*>(cf_ring + 2 * (size_t)PB) + (size_t)img * TN;
+    unsigned* Ms = reinterpret_cast<unsigned*>(reinterpret_cast<double*>(cf_ring + 2 * (size_t)PB) + 2 * (size_t)TN) + (size_t)img * TN;
 
     // ---- stage in: zero pads, the line at offset 4r (flagging.py:392-395) ----
-    for (int k = l; k < PB; k += 256) {
+    for (int k = l; k < PB; k += NTI) {
         if (k < 4 * r || k >= P) X[k] = 0.0f;
     }
-    for (int k = 256 + l; k < BOXX_TN; k += 256) { Ts[k] = 0.0; Ms[k] = 0xFFFFFFFFu; }
+    for (int k = NTI + l; k < TN; k += NTI) { Ts[k] = 0.0; Ms[k] = 0xFFFFFFFFu; }
     {
         const float* src = srcW + win * sws_img + (size_t)(img ? img_gap : 0u) + (size_t)line * ld;
-        for (int q = l; q < n / 4; q += 256) {
+        for (int q = l; q < n / 4; q += NTI) {
             const float4 v = reinterpret_cast<const float4*>(src)[q];
             float* px = X + 4 * r + 4 * q;                      // (4r + 4q: 16-byte aligned)
             *reinterpret_cast<float4*>(px) = v;
@@ -91,8 +102,10 @@ k_boxx(const float* __restrict__ srcW, unsigned img_gap, const float* __restrict
     const int d = R2 + 1;
     const int a = d / L, m = d - a * L;                        // whole chunks in a window, length of the partial one
     const int i0 = l * L;
-    double od[L];                                              // the thread's chunk of the current image state, as float64
-    float on[L];
+    // the thread's chunk of the current image state: as float64 on the short chunks (saves a conversion per position
+    // and pass), as float32 on the long ones (half the registers)
+    using ST = typename std::conditional<(L > 32), float, double>::type;
+    ST od[L];
     bool bad;                                                  // a term that is negative, infinite or NaN
     // own chunk from LDS -> registers, totals, smallest non-zero term (as bits - 1: zero wraps to the maximum)
     auto rescan = [&]() {
@@ -104,8 +117,8 @@ k_boxx(const float* __restrict__ srcW, unsigned img_gap, const float* __restrict
             const unsigned b = __float_as_uint(v);
             mn = min(mn, b - 1u);
             mx = max(mx, b);
-            od[k] = (double)v;
-            T += od[k];
+            od[k] = (ST)v;
+            T += (double)v;
         }
         bad = mx >= 0x7F800000u;
         Ts[l] = T; Ms[l] = mn;
@@ -127,20 +140,25 @@ k_boxx(const float* __restrict__ srcW, unsigned img_gap, const float* __restrict
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int c = c0 + u;
-                tv[u] = Ts[c < a ? l + c : BOXX_TN - 1];
-                mv[u] = Ms[c < a + 2 ? l + c : BOXX_TN - 1];
+                tv[u] = Ts[c < a ? l + c : TN - 1];
+                mv[u] = Ms[c < a + 2 ? l + c : TN - 1];
             }
             acc += ((tv[0] + tv[1]) + (tv[2] + tv[3])) + ((tv[4] + tv[5]) + (tv[6] + tv[7]));
             mw = min(mw, min(min(min(mv[0], mv[1]), min(mv[2], mv[3])), min(min(mv[4], mv[5]), min(mv[6], mv[7]))));
         }
         {
-            const int e0 = i0 + a * L;                         // the m positions after the whole chunks
-            for (int j0 = 0; j0 < m; j0 += 4) {
+            // the m positions after the a whole chunks -- or one more whole chunk less its last L - m positions
+            const bool less = L - m < m;
+            const int cnt = less ? L - m : m;
+            const int e0 = i0 + a * L + (less ? m : 0);
+            double part = 0.0;
+            for (int j0 = 0; j0 < cnt; j0 += 4) {
                 float xv[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) xv[u] = X[j0 + u < m ? e0 + j0 + u : PB - 1];
-                acc += ((double)xv[0] + (double)xv[1]) + ((double)xv[2] + (double)xv[3]);
+                for (int u = 0; u < 4; u++) xv[u] = X[j0 + u < cnt ? e0 + j0 + u : PB - 1];
+                part += ((double)xv[0] + (double)xv[1]) + ((double)xv[2] + (double)xv[3]);
             }
+            acc = less ? (acc + Ts[l + a]) - part : acc + part;
         }
         const double bound = acc + Ts[l + a] + Ts[l + a + 1];
         // exact if bound < 2^53 * 2^(e_m - 23): with biased exponent fields EB (float64, 1023) and Em (float32, 127, at
@@ -158,26 +176,35 @@ k_boxx(const float* __restrict__ srcW, unsigned img_gap, const float* __restrict
         const bool fail = votes && (bad || (mw != 0xFFFFFFFFu && EB - Em > 924));
 
         // ---- the pass, fast form: recurrence along the chunk ----
-        float far[L];
-#pragma unroll
-        for (int k = 0; k < L - 1; k++) far[k] = X[i0 + k + 1 + R2];
+        // (in groups of BOXX_G positions, each with its own LDS reads: the scheduler would otherwise convert every
+        //  far sample to float64 up front and run out of registers on the long chunks)
         double T = 0.0;
         unsigned mn = 0xFFFFFFFFu;
 #pragma unroll
-        for (int k = 0; k < L; k++) {
-            const float ov = (float)acc;                       // flagging.py:410: the pass stores float32
-            if (k < L - 1) acc += (double)far[k] - od[k];      // (exact: any order)
-            on[k] = ov;
-            od[k] = (double)ov;                                // (a failed pass reloads od[] from the line: rescan())
-            T += od[k];
-            mn = min(mn, __float_as_uint(ov) - 1u);
+        for (int g0 = 0; g0 < L; g0 += BOXX_G) {
+            float far[BOXX_G];
+#pragma unroll
+            for (int u = 0; u < BOXX_G; u++)
+                if (g0 + u < L - 1) far[u] = X[i0 + g0 + u + 1 + R2];
+#pragma unroll
+            for (int u = 0; u < BOXX_G; u++) {
+                const int k = g0 + u;
+                if (k < L) {
+                    const float ov = (float)acc;               // flagging.py:410: the pass stores float32
+                    if (k < L - 1) acc += (double)far[u] - (double)od[k];   // (exact: any order)
+                    od[k] = (ST)ov;                            // (a failed pass reloads od[] from the line: rescan())
+                    T += (double)ov;
+                    mn = min(mn, __float_as_uint(ov) - 1u);
+                }
+            }
+            if (L > 32) __builtin_amdgcn_sched_barrier(0);
         }
         // every far read of the workgroup is done before anybody overwrites the line; the same barrier tells
         // whether some thread's exactness condition failed
         const int anyfail = __syncthreads_or(fail ? 1 : 0);
         if (!anyfail) {
 #pragma unroll
-            for (int k = 0; k < L; k++) X[i0 + k] = on[k];
+            for (int k = 0; k < L; k++) X[i0 + k] = (float)od[k];   // (exact: od[k] is a float32 value)
             Ts[l] = T; Ms[l] = mn;
             bad = false;                                       // (finite, non-negative: float32 of an exact sum of such terms)
         } else {
@@ -212,7 +239,7 @@ k_boxx(const float* __restrict__ srcW, unsigned img_gap, const float* __restrict
     float* arow = outA + win * ws_outA + (size_t)line * ld;
     float* brow = MODE == 2 ? outB + win * ws_outB + (size_t)line * ld : nullptr;
     bool line_nan = false;
-    for (int q = tid; q < n / 4; q += 512) {
+    for (int q = tid; q < n / 4; q += 2 * NTI) {
         const float4 w4 = *reinterpret_cast<const float4*>(Xw + 4 * q);
         const float4 o4 = *reinterpret_cast<const float4*>(Xo + 4 * q);
         float4 d4 = reinterpret_cast<const float4*>(drow)[q];

@@ -1041,36 +1041,44 @@ thread_local unsigned long long g_boxx_last_stats[2] = {0, 0};
 #ifndef BOXX_MIN_R
 #define BOXX_MIN_R 56
 #endif
+// chunk length (low 8 bits) and threads per image (128 or 256, << 8) for a line of n positions, or 0.
+// Long chunks on 128 threads per image where the line fits them (fewer instructions per line: see the kernel);
+// TRI_BOXX_NTI=256 forces the short chunks (A/B runs).
 int boxx_pick_l(int rad, int n) {
     static const bool env_off = [] { const char* e = getenv("TRI_FILTER_NO_EXACT"); return e && e[0] == '1'; }();
+    static const int force_nti = [] { const char* e = getenv("TRI_BOXX_NTI"); return e ? atoi(e) : 0; }();
     if (g_boxx_override == 0 || (g_boxx_override < 0 && (env_off || rad < BOXX_MIN_R))) return 0;
     if (rad < 1 || n % 4 != 0) return 0;
     const int64_t P = (int64_t)n + 4 * (int64_t)rad;
-    for (int L : {17, 19, 21, 25}) {
-        if (256 * (int64_t)L < P || L > 2 * rad + 1 || (2 * rad + 1) / L > BOXX_AMAX) continue;
-        if (boxx_lds_bytes(L, rad) > 159 * 1024) continue;
-        return L;
+    struct Cand { int nti, l; };
+    static const Cand cands[] = {{128, 37}, {128, 41}, {256, 17}, {256, 19}, {256, 21}, {256, 25}};
+    for (const Cand& c : cands) {
+        if (force_nti && c.nti != force_nti) continue;
+        if (c.nti == 128 && (P <= 128 * 17 || rad < 64)) continue;        // (short lines / small radii: the short chunks do)
+        if ((int64_t)c.nti * c.l < P || c.l > 2 * rad + 1 || (2 * rad + 1) / c.l > BOXX_AMAX) continue;
+        if (boxx_lds_bytes(c.nti, c.l, rad) > 159 * 1024) continue;
+        return c.l | (c.nti << 8);
     }
     return 0;
 }
 // the reciprocal division is verified exhaustively for these radii only (test_division_by_box_denominator)
 static bool boxx_recip_ok(int rad) { return rad <= 128 || rad == 166 || rad == 221 || rad == 277 || rad == 397 || rad == 795; }
 
-template <int L, int MODE>
+template <int NTI, int L, int MODE>
 int launch_boxx_l(const Run& r, const float* srcW, unsigned gap, const float* data, const uint8_t* mask, float* outA, float* outB,
                   int n, int C, int ld, int rad, size_t sws_img, size_t ws_data, size_t ws_mask, size_t ws_outA, size_t ws_outB,
                   int64_t W, uint8_t* nanflag, unsigned long long* stats) {
     const BoxDenom denom = box_reciprocal(box_denominator(rad));
-    const size_t lds = boxx_lds_bytes(L, rad);
+    const size_t lds = boxx_lds_bytes(NTI, L, rad);
     dim3 grid((unsigned)C, (unsigned)W);
+    // (the kernel also has a few static LDS bytes -- __syncthreads_or -- so ask for what this launch needs, not for 160 KB)
     if (boxx_recip_ok(rad)) {
-        // (the kernel also has a few static LDS bytes -- __syncthreads_or -- so ask for what this launch needs, not for 160 KB)
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boxx<L, MODE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_boxx<L, MODE, true>), grid, dim3(512), lds, r.st, srcW, gap, data, mask, outA, outB, n, ld, rad, denom, sws_img,
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boxx<NTI, L, MODE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_boxx<NTI, L, MODE, true>), grid, dim3(2 * NTI), lds, r.st, srcW, gap, data, mask, outA, outB, n, ld, rad, denom, sws_img,
                            ws_data, ws_mask, ws_outA, ws_outB, nanflag, stats);
     } else {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boxx<L, MODE, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_boxx<L, MODE, false>), grid, dim3(512), lds, r.st, srcW, gap, data, mask, outA, outB, n, ld, rad, denom, sws_img,
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boxx<NTI, L, MODE, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_boxx<NTI, L, MODE, false>), grid, dim3(2 * NTI), lds, r.st, srcW, gap, data, mask, outA, outB, n, ld, rad, denom, sws_img,
                            ws_data, ws_mask, ws_outA, ws_outB, nanflag, stats);
     }
     LAUNCHCHK();
@@ -1088,13 +1096,13 @@ int launch_boxx(const Run& r, int L, const float* srcW, const float* srcO, const
         (MODE == 2 && (((uintptr_t)outB % 16 != 0) || ws_outB % 4 != 0)) || C > 65535 * 1024)
         return set_err(TRI_EUNSUPPORTED, "exact row filter: unaligned images");
     const unsigned gap = (unsigned)(srcO - srcW);
+#define BOXX_CASE(NTI, LL) case ((NTI) << 8 | (LL)): return launch_boxx_l<NTI, LL, MODE>(r, srcW, gap, data, mask, outA, outB, n, C, ld, rad, sws_img, ws_data, ws_mask, ws_outA, ws_outB, W, nanflag, stats);
     switch (L) {
-        case 17: return launch_boxx_l<17, MODE>(r, srcW, gap, data, mask, outA, outB, n, C, ld, rad, sws_img, ws_data, ws_mask, ws_outA, ws_outB, W, nanflag, stats);
-        case 19: return launch_boxx_l<19, MODE>(r, srcW, gap, data, mask, outA, outB, n, C, ld, rad, sws_img, ws_data, ws_mask, ws_outA, ws_outB, W, nanflag, stats);
-        case 21: return launch_boxx_l<21, MODE>(r, srcW, gap, data, mask, outA, outB, n, C, ld, rad, sws_img, ws_data, ws_mask, ws_outA, ws_outB, W, nanflag, stats);
-        case 25: return launch_boxx_l<25, MODE>(r, srcW, gap, data, mask, outA, outB, n, C, ld, rad, sws_img, ws_data, ws_mask, ws_outA, ws_outB, W, nanflag, stats);
+        BOXX_CASE(128, 37) BOXX_CASE(128, 41)
+        BOXX_CASE(256, 17) BOXX_CASE(256, 19) BOXX_CASE(256, 21) BOXX_CASE(256, 25)
     }
-    return set_err(TRI_EINVAL, "no exact row filter for chunks of %d", L);
+#undef BOXX_CASE
+    return set_err(TRI_EINVAL, "no exact row filter for code %d", L);
 }
 
 // Lane-per-stage variant of the same (radii 17..LANE4_R_MAX): k_colfilter_lane4<3, *>.
@@ -1964,7 +1972,7 @@ extern "C" int tri_bench_boxfilter(const float* data, const uint8_t* flags4, flo
         g_boxx_last_stats[0] = h[0];
         g_boxx_last_stats[1] = h[1];
         if (const char* e = getenv("TRI_BOXX_STATS")) if (e[0] == '1')
-            fprintf(stderr, "k_boxx r=%d L=%d: %llu line passes, %llu redone sequentially\n", (int)radius, xl, h[0], h[1]);
+            fprintf(stderr, "k_boxx r=%d L=%d x %d threads: %llu line passes, %llu redone sequentially\n", (int)radius, xl & 255, xl >> 8, h[0], h[1]);
         (void)hipFree(x_data_tf);
         (void)hipFree(x_stats);
     }
