@@ -132,10 +132,24 @@ def cpu_baseline(kw, T, F, seconds_budget=25.0, chain=None):
     oracle.set_modes(oracle.POW_SQMUL, oracle.INTERP_F64)
     nproc = os.cpu_count() or 1
     try:
-        nproc = len(os.sched_getaffinity(0))     # the cores this process may actually run on
+        nproc = len(os.sched_getaffinity(0))     # the cores this process may run on
     except (AttributeError, OSError):
         pass
-    cores = int(os.environ.get("TRI_BENCH_CPU_THREADS", nproc))
+    # ... and the CPU time it may use: a container's cgroup quota (cpu.max: "<quota> <period>" in microseconds) can be
+    # far below the host's core count -- threads beyond it only take turns (256 threads on a 16-core share: 10 x slower)
+    quota = None
+    for path, v2 in (("/sys/fs/cgroup/cpu.max", True), ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", False)):
+        try:
+            txt = open(path).read().split()
+            if v2 and txt[0] != "max":
+                quota = float(txt[0]) / float(txt[1])
+            elif not v2 and float(txt[0]) > 0:
+                quota = float(txt[0]) / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    usable = nproc if quota is None else max(1, min(nproc, int(quota + 0.5)))
+    cores = int(os.environ.get("TRI_BENCH_CPU_THREADS", usable))
 
     def run(vis, flags, threads):
         t0 = time.time()
@@ -161,9 +175,11 @@ def cpu_baseline(kw, T, F, seconds_budget=25.0, chain=None):
     vis, flags = synth_host_windows(nwin, T, F)
     dt, out = run(vis, flags, cores)
     what = "chain (flag_nans_zeros, uvcontsub, sum_threshold)" if chain is not None else "same kwargs"
-    res = dict(value=round(nwin * T * F / dt / 1e6, 3), unit="Mvis/s", cores=cores, nproc=nproc, kind="port",
-               sample="%d windows of %dx%d (1 corr), %s, %.1f s on %d threads (host has %d cores); C restatement "
-                      "of the reference numba path (oracle/), OpenMP over windows" % (nwin, T, F, what, dt, cores, nproc))
+    res = dict(value=round(nwin * T * F / dt / 1e6, 3), unit="Mvis/s", cores=cores, nproc=nproc,
+               cpu_quota=None if quota is None else round(quota, 2), kind="port",
+               sample="%d windows of %dx%d (1 corr), %s, %.1f s on %d threads (host shows %d cores, cgroup CPU quota %s); "
+                      "C restatement of the reference numba path (oracle/), OpenMP over windows"
+                      % (nwin, T, F, what, dt, cores, nproc, "none" if quota is None else "%.1f cores" % quota))
     return res, vis, flags, out
 
 

@@ -4,7 +4,10 @@
 //   kernels_elementwise.hpp   K1, K2, K5, K6, K8, pack / unpack, strategy steps
 //   kernels_median.hpp        K3  exact medians
 //   kernels_boxfilter.hpp     K4  box-Gaussian filter (four forms)
+//   kernels_boxline.hpp / kernels_boxpipe.hpp   K4r register delay lines, K4p / K4q / K4qf stage pipelines
+//   kernels_boxexact.hpp      K4x exact row filter for any radius (LDS-resident line, checked exactness)
 //   kernels_sumthreshold.hpp  K7  fused SumThreshold
+#include <unordered_set>
 #include "tri_common.hpp"
 #include "kernels_elementwise.hpp"
 #include "kernels_median.hpp"
@@ -18,6 +21,21 @@
 // host side
 // ===========================================================================
 namespace {
+
+// Opt-in to more than 64 KB of dynamic LDS for one kernel.  The attribute belongs to the (kernel, device) pair and a
+// process may drive several devices (one calling thread per device): it is set once per calling thread, kernel
+// and device -- not once per process -- and a transient failure is not cached.
+static hipError_t lds_optin(const void* fn, hipFuncAttribute attr, int value) {
+    thread_local std::unordered_set<uint64_t> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t key = (uint64_t)(uintptr_t)fn * 64u + (uint64_t)(dev & 63);
+    if (done.count(key)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, attr, value);
+    if (e == hipSuccess) done.insert(key);
+    return e;
+}
 
 struct Bump {
     char* base;
@@ -511,9 +529,9 @@ int launch_boxt_ks(const Run& r, const float* srcData, const uint8_t* srcFlags, 
     const int d = 2 * rad - KS;
     const size_t lds = (size_t)4 * d * 64 * sizeof(float);
     dim3 grid((unsigned)cdiv(C, 64), (unsigned)W);
-    static const hipError_t attr = [] {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boxt<KS, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boxt<KS, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const hipError_t attr = [] {
+        hipError_t e = lds_optin(reinterpret_cast<const void*>(&k_boxt<KS, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = lds_optin(reinterpret_cast<const void*>(&k_boxt<KS, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return e;
     }();
     HIPCHK(attr);
@@ -536,7 +554,7 @@ int launch_boxt_spec_ks(const Run& r, const float* srcData, const uint8_t* srcFl
     const int d = 2 * rad - KS;
     const size_t lds = (size_t)4 * d * 64 * sizeof(float);
     dim3 grid((unsigned)cdiv(C, 64), 2);
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boxt_spec<KS, true>),
+    const hipError_t attr = lds_optin(reinterpret_cast<const void*>(&k_boxt_spec<KS, true>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     HIPCHK(attr);
     if (d > 0) hipLaunchKernelGGL((k_boxt_spec<KS, true>), grid, dim3(64), lds, r.st, srcData, srcFlags, dstW, dstO, n, C, rad, denom);
@@ -572,7 +590,7 @@ static int boxp_pick_block(int rad, int C) {
 template <int B, int P>
 int launch_boxp_spec_b(const Run& r, const float* srcData, const uint8_t* srcFlags, float* dstW, float* dstO,
                        int n, int C, int rad, float denom) {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boxp_spec<B, P>),
+    const hipError_t attr = lds_optin(reinterpret_cast<const void*>(&k_boxp_spec<B, P>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     HIPCHK(attr);
     dim3 grid((unsigned)cdiv(C, 64), 2);
@@ -597,9 +615,9 @@ static int boxq_pick_ks(int rad) {
 template <int KS>
 int launch_boxq_ks(const Run& r, const float* srcData, const uint8_t* srcFlags, float* dstW, float* dstO,
                    int n, int C, int rad, float denom, size_t sws, size_t dws, int64_t W) {
-    static const hipError_t attr = [] {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boxq<KS, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boxq<KS, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const hipError_t attr = [] {
+        hipError_t e = lds_optin(reinterpret_cast<const void*>(&k_boxq<KS, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = lds_optin(reinterpret_cast<const void*>(&k_boxq<KS, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return e;
     }();
     HIPCHK(attr);
@@ -666,12 +684,12 @@ int launch_colfilter(const Run& r, int srcmode, float* bufW, float* bufO, const 
         size_t lds = (size_t)lane4_ring_capacity(rad) * 64 * sizeof(float);
         dim3 grid((unsigned)cdiv(C, 16), (unsigned)W, 2);
         // thread-safe one-time setup (C++11 static initialisation)
-        static const hipError_t attr4 = [] {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lane4<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lane4<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lane4<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lane4<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lane4<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const hipError_t attr4 = [] {
+            hipError_t e = lds_optin(reinterpret_cast<const void*>(&k_colfilter_lane4<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = lds_optin(reinterpret_cast<const void*>(&k_colfilter_lane4<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = lds_optin(reinterpret_cast<const void*>(&k_colfilter_lane4<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = lds_optin(reinterpret_cast<const void*>(&k_colfilter_lane4<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = lds_optin(reinterpret_cast<const void*>(&k_colfilter_lane4<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             return e;
         }();
         HIPCHK(attr4);
@@ -710,13 +728,13 @@ int launch_colfilter(const Run& r, int srcmode, float* bufW, float* bufO, const 
     if (bt > 0) {
         size_t lds = (size_t)4 * 2 * rad * bt * sizeof(float);
         dim3 grid((unsigned)cdiv(C, bt), (unsigned)W, 2);
-        static const hipError_t attr_set = [] {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<0, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<1, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<1, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<2, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds<2, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const hipError_t attr_set = [] {
+            hipError_t e = lds_optin(reinterpret_cast<const void*>(&k_colfilter_lds<0, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = lds_optin(reinterpret_cast<const void*>(&k_colfilter_lds<1, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = lds_optin(reinterpret_cast<const void*>(&k_colfilter_lds<1, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = lds_optin(reinterpret_cast<const void*>(&k_colfilter_lds<1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = lds_optin(reinterpret_cast<const void*>(&k_colfilter_lds<2, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = lds_optin(reinterpret_cast<const void*>(&k_colfilter_lds<2, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             return e;
         }();
         HIPCHK(attr_set);
@@ -785,7 +803,7 @@ int launch_colst(const Run& r, const StWin& sw, const float* data, const double*
                                d_chunk_ends, fa, thr_scale, L, C, G, ws_data, ws_out);
     } else if (st_use_pipe(sw)) {
         // any list of up to eight windows: one window per wave, lagging twin accumulators (K7p)
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colst_pipe),
+        const hipError_t attr = lds_optin(reinterpret_cast<const void*>(&k_colst_pipe),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         HIPCHK(attr);
         dim3 gridp((unsigned)cdiv(C, 64), (unsigned)G, (unsigned)W);
@@ -882,9 +900,9 @@ int launch_colfilter_t(const Run& r, const float* srcW, const float* srcO, float
                        int n, int C, int ld, int rad, size_t sws_img, size_t dws, int64_t W, float* deferred_denom) {
     float denom = box_denominator(rad);
     size_t lds = ((size_t)4 * 2 * rad * CFT_BT + (size_t)CFT_PF * (CFT_BT + 1)) * sizeof(float);
-    static const hipError_t attr = [] {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds_t<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds_t<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const hipError_t attr = [] {
+        hipError_t e = lds_optin(reinterpret_cast<const void*>(&k_colfilter_lds_t<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = lds_optin(reinterpret_cast<const void*>(&k_colfilter_lds_t<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return e;
     }();
     HIPCHK(attr);
@@ -913,7 +931,7 @@ int launch_colfilter_tf(const Run& r, const float* srcW, const float* srcO, floa
                         int n, int C, int ld, int rad, size_t sws_img, size_t dws, size_t ws_data, int64_t W, uint8_t* nanflag) {
     float denom = box_denominator(rad);
     size_t lds = (size_t)2 * ((size_t)4 * 2 * rad * CFF_BT + (size_t)CFT_PF * (CFF_BT + 1)) * sizeof(float);
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lds_tf<MODE>),
+    const hipError_t attr = lds_optin(reinterpret_cast<const void*>(&k_colfilter_lds_tf<MODE>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     HIPCHK(attr);
     dim3 grid((unsigned)cdiv(C, CFF_BT), (unsigned)W);
@@ -934,7 +952,7 @@ int launch_boxf_ks(const Run& r, const float* srcW, const float* srcO, float* ds
     if (srcO <= srcW || ((uint64_t)(srcO - srcW) + (uint64_t)C * ld) * 4u >= (1ull << 31))
         return set_err(TRI_EUNSUPPORTED, "fused frequency stage: the data image must follow the weight image within 2^31 bytes");
     const unsigned gap = (unsigned)(srcO - srcW);
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boxf<KS, true, MODE>),
+    const hipError_t attr = lds_optin(reinterpret_cast<const void*>(&k_boxf<KS, true, MODE>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     HIPCHK(attr);
     dim3 grid((unsigned)cdiv(C, 32), (unsigned)W);
@@ -943,7 +961,7 @@ int launch_boxf_ks(const Run& r, const float* srcW, const float* srcO, float* ds
     bool one_wave = false;
     if constexpr (KS == 32) {
         if (d > 14) {
-            static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boxf<KS, true, MODE, 1>),
+            const hipError_t attr1 = lds_optin(reinterpret_cast<const void*>(&k_boxf<KS, true, MODE, 1>),
                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             HIPCHK(attr1);
             hipLaunchKernelGGL((k_boxf<KS, true, MODE, 1>), grid, dim3(64), lds, r.st, srcW, gap, dstW, dstO, data, n, C, ld, rad,
@@ -977,7 +995,7 @@ extern thread_local int g_boxq_override;
 template <int KS, int MODE, int B = 16>
 int launch_boxqf_ks(const Run& r, const float* srcW, unsigned gap, float* dstW, float* dstO, const float* data,
                     int n, int C, int ld, int rad, size_t sws_img, size_t dws, size_t ws_data, int64_t W, uint8_t* nanflag) {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boxqf<KS, MODE, B>),
+    const hipError_t attr = lds_optin(reinterpret_cast<const void*>(&k_boxqf<KS, MODE, B>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     HIPCHK(attr);
     const BoxDenom denom = box_reciprocal(box_denominator(rad));
@@ -1071,13 +1089,13 @@ int launch_boxx_l(const Run& r, const float* srcW, unsigned gap, const float* da
     const BoxDenom denom = box_reciprocal(box_denominator(rad));
     const size_t lds = boxx_lds_bytes(NTI, L, rad);
     dim3 grid((unsigned)C, (unsigned)W);
-    // (the kernel also has a few static LDS bytes -- __syncthreads_or -- so ask for what this launch needs, not for 160 KB)
+    // (the kernel also has a few static LDS bytes -- __syncthreads_or -- so 160 KB of dynamic LDS is refused: ask for 159)
     if (boxx_recip_ok(rad)) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boxx<NTI, L, MODE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(lds_optin(reinterpret_cast<const void*>(&k_boxx<NTI, L, MODE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
         hipLaunchKernelGGL((k_boxx<NTI, L, MODE, true>), grid, dim3(2 * NTI), lds, r.st, srcW, gap, data, mask, outA, outB, n, ld, rad, denom, sws_img,
                            ws_data, ws_mask, ws_outA, ws_outB, nanflag, stats);
     } else {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boxx<NTI, L, MODE, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(lds_optin(reinterpret_cast<const void*>(&k_boxx<NTI, L, MODE, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
         hipLaunchKernelGGL((k_boxx<NTI, L, MODE, false>), grid, dim3(2 * NTI), lds, r.st, srcW, gap, data, mask, outA, outB, n, ld, rad, denom, sws_img,
                            ws_data, ws_mask, ws_outA, ws_outB, nanflag, stats);
     }
@@ -1115,9 +1133,9 @@ int launch_colfilter_t4(const Run& r, const float* srcW, const float* srcO, floa
                         int n, int C, int ld, int rad, size_t sws_img, size_t dws, int64_t W, float* deferred_denom) {
     float denom = box_denominator(rad);
     size_t lds = ((size_t)lane4_ring_capacity(rad) * 64 + 32 * 17) * sizeof(float);
-    static const hipError_t attr = [] {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lane4<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colfilter_lane4<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const hipError_t attr = [] {
+        hipError_t e = lds_optin(reinterpret_cast<const void*>(&k_colfilter_lane4<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = lds_optin(reinterpret_cast<const void*>(&k_colfilter_lane4<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return e;
     }();
     HIPCHK(attr);
@@ -1846,7 +1864,7 @@ extern "C" int tri_bench_sumthreshold(const float* data, const double* mad, uint
     if (variant == 0 && can_fuse) variant = st_use_mask(L, C) ? 3 : 2;
     if (variant == 4) {
         if (sw.nw > 8 || stp_lds_bytes(sw) > 160 * 1024) return set_err(TRI_EUNSUPPORTED, "stage pipeline: more than eight windows, or the flag ring does not fit LDS");
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colst_pipe), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(lds_optin(reinterpret_cast<const void*>(&k_colst_pipe), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     bool fused = variant == 2;
     StFusedArgs fa;

@@ -13,6 +13,7 @@ There is no CPU path: without a GPU (or without the built extension) the
 call raises ``RuntimeError``.
 """
 import ctypes as C
+import collections
 import os
 import threading
 import time
@@ -73,25 +74,40 @@ def prepare_params(ntime, nchan, outlier_nsigma=4.5,
     return p
 
 
+_WS_CACHE_MAX = 3       # cached workspaces per thread and device (least recently used goes first)
+
+
 def _workspace(torch, device, nbytes):
     """Per-thread, per-device, per-STREAM workspace tensor (grown on demand): calls from the
     threads of a dask ThreadPool never share scratch memory, and neither do two pipelines
-    that one thread has in flight on different streams."""
+    that one thread has in flight on different streams.  The cache is a small LRU: a thread
+    that rotates through many streams keeps at most _WS_CACHE_MAX workspaces per device alive
+    (a stream handle can also be recycled by the runtime after its stream is destroyed, so an
+    old entry must not live forever); before a workspace GROWS, the thread's other workspaces
+    on that device are dropped -- the new one was sized against the memory they hold.  Callers
+    that create and destroy streams freely should call release_workspace() when done."""
     cache = getattr(_tls, "ws", None)
     if cache is None:
-        cache = _tls.ws = {}
+        cache = _tls.ws = collections.OrderedDict()
     key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     t = cache.get(key)
-    if t is None or t.numel() < nbytes:
-        cache[key] = None
-        t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        cache[key] = t
+    if t is not None and t.numel() >= nbytes:
+        cache.move_to_end(key)
+        return t
+    for k in [k for k in cache if k[:2] == key[:2]]:
+        del cache[k]
+    t = None
+    t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    cache[key] = t
+    mine = [k for k in cache if k[:2] == key[:2]]
+    for k in mine[:-_WS_CACHE_MAX]:
+        del cache[k]
     return t
 
 
 def release_workspace():
     """Drops this thread's cached device workspaces."""
-    _tls.ws = {}
+    _tls.ws = collections.OrderedDict()
 
 
 def set_num_threads(n):
@@ -111,13 +127,14 @@ def _workspace_budget(torch, device):
     if env:
         return int(float(env) * (1 << 30))
     free, total = torch.cuda.mem_get_info(device)
-    cached = [t for k, t in getattr(_tls, "ws", {}).items() if t is not None and k[:2] == (device.type, device.index)]
-    have = max([t.numel() for t in cached], default=0)
+    # what this thread already holds on the device can be reused or released: it counts as available
+    have = sum(t.numel() for k, t in getattr(_tls, "ws", {}).items() if t is not None and k[:2] == (device.type, device.index))
     nthreads = _declared_threads or int(os.environ.get("TRICOLOUR_AMD_THREADS", "0") or 0)
     if nthreads > 1:
-        # a fixed share of the device, whatever is free right now
-        return max(int(0.6 * total / nthreads), have)
-    return max(int(0.6 * free), have)
+        # a fixed share of the device -- but never more than what is actually free right now (the caller's own
+        # slabs, other processes): the batch shrinks instead of the allocation failing
+        return max(min(int(0.6 * total / nthreads), int(0.9 * free) + have), 0)
+    return int(0.6 * (free + have))
 
 
 def _pick_batch(lib, p, n_cp, T, F, budget):
