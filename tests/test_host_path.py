@@ -109,3 +109,45 @@ def test_numpy_result_paths_agree(gpu, oracle, monkeypatch):
     with ThreadPoolExecutor(3) as pool:
         outs = list(pool.map(run, range(3)))
     assert all(np.array_equal(o, exp) for o in outs)
+
+
+@pytest.mark.gpu
+def test_numpy_block_pipelined_inside_the_call(gpu, oracle):
+    """A numpy block of >= 32 windows is cut into pieces along the baseline axis and pipelined inside the call (copy of
+    piece i + 1 under the kernels of piece i, two side streams): same flags as the oracle and as the one-piece path,
+    ragged piece sizes, repeated calls, and calls from several threads at once."""
+    import threading
+    from tricolour_amd import flagging
+    rs = np.random.RandomState(12)
+    shape = (11, 4, 32, 64)                      # 44 windows: two pieces of 5 / 6 baselines
+    vis = (rs.standard_normal(shape) + 1j * rs.standard_normal(shape)).astype(np.complex64)
+    vis[..., 30] *= 7
+    vis[4, 2, 9] *= 5
+    vis[7, 1, 3, 5] = np.nan
+    flags = rs.uniform(size=shape) < 0.03
+    kw = dict(num_major_iterations=2, background_iterations=2)
+    exp = oracle.sum_threshold_flagger(vis, flags, **kw)
+    assert flagging._PIPELINE_PIECES > 1
+    v0, f0 = vis.copy(), flags.copy()
+    for _ in range(2):
+        got = gpu.sum_threshold_flagger(vis, flags, **kw)
+        assert got.dtype == np.bool_ and got.shape == shape and np.array_equal(got, exp)
+    assert np.array_equal(vis.view(np.uint64), v0.view(np.uint64)) and np.array_equal(flags, f0)   # inputs untouched
+    old = flagging._PIPELINE_PIECES
+    try:
+        flagging._PIPELINE_PIECES = 1
+        one = gpu.sum_threshold_flagger(vis, flags, **kw)
+    finally:
+        flagging._PIPELINE_PIECES = old
+    assert np.array_equal(one, exp)
+    results, errors = [None] * 3, []
+
+    def work(i):
+        try:
+            results[i] = gpu.sum_threshold_flagger(vis, flags, **kw)
+        except Exception as e:   # pragma: no cover
+            errors.append(e)
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors and all(np.array_equal(r, exp) for r in results)

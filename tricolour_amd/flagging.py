@@ -28,6 +28,19 @@ _H2D_TURN = threading.Lock()
 _D2H_TURN = _H2D_TURN
 _LINK_TURNS = os.environ.get("TRICOLOUR_AMD_LINK_TURNS", "1") != "0"
 _TRACE = [] if os.environ.get("TRICOLOUR_AMD_TRACE") == "1" else None   # (debug) per-call phase times
+# numpy blocks are cut into up to this many pieces along the baseline axis and pipelined inside the call
+# (copy of piece i + 1 under the kernels of piece i); TRICOLOUR_AMD_PIPELINE=1 keeps a block in one piece
+# (2 pieces measured best for one calling thread: 128 -> 102 ms per 16-baseline block; 4 pieces: 110 ms, the launches get
+# too small.  When other threads have calls in flight their blocks already overlap each other's copies: no cutting then.)
+_PIPELINE_PIECES = int(os.environ.get("TRICOLOUR_AMD_PIPELINE", "2") or 1)
+_PIPELINE_MIN_WINDOWS = 16         # (bl, corr) windows per piece at least: smaller launches no longer fill the device
+_INFLIGHT = [0]                    # numpy-block calls currently inside the library (all threads)
+_INFLIGHT_LOCK = threading.Lock()
+_LAST_CALLER = [None, 0.0]         # (thread id, time) of the latest numpy-block call
+# TRICOLOUR_AMD_PINNED_RESULTS=1: numpy results are views of pinned host tensors from torch's caching host allocator --
+# the flags then land in the result array at the link rate, without the 20 ms CPU copy into freshly mapped pages per
+# 16-baseline block.  Opt-in: every result the caller keeps alive pins its memory.
+_PINNED_RESULTS = os.environ.get("TRICOLOUR_AMD_PINNED_RESULTS", "0") == "1"
 
 
 def _torch():
@@ -284,6 +297,27 @@ def sum_threshold_flagger(vis, flags, outlier_nsigma=4.5,
                        average_freq, flag_all_time_frac, flag_all_freq_frac, rho,
                        num_major_iterations)
     torch = _require_gpu()
+    if _debug is None and isinstance(vis, np.ndarray) and isinstance(flags, np.ndarray):
+        me, now = threading.get_ident(), time.time()
+        with _INFLIGHT_LOCK:
+            _INFLIGHT[0] += 1
+            # alone: nobody else inside, and no other thread was here within the last two seconds (a pool of
+            # threads taking blocks one after the other overlaps their copies by itself)
+            alone = _INFLIGHT[0] == 1 and (_LAST_CALLER[0] in (None, me) or now - _LAST_CALLER[1] > 2.0)
+            _LAST_CALLER[0], _LAST_CALLER[1] = me, now
+        try:
+            if (alone and _PIPELINE_PIECES > 1 and nbl >= 2 and nbl * ncorr >= 2 * _PIPELINE_MIN_WINDOWS
+                    and ntime > 0 and nchan > 0):
+                return _flag_numpy_pipelined(torch, lib, p, vis, flags, average_freq)
+            return _flag_host_call(torch, lib, p, vis, flags, average_freq, _debug)
+        finally:
+            with _INFLIGHT_LOCK:
+                _INFLIGHT[0] -= 1
+                _LAST_CALLER[1] = time.time()
+    return _flag_host_call(torch, lib, p, vis, flags, average_freq, _debug)
+
+
+def _flag_host_call(torch, lib, p, vis, flags, average_freq, _debug):
     side = _host_call_stream(torch, vis, flags)
     if side is not None:
         caller = torch.cuda.current_stream(side.device)
@@ -299,7 +333,56 @@ def sum_threshold_flagger(vis, flags, outlier_nsigma=4.5,
     return _flag_on_current_stream(torch, lib, p, vis, flags, average_freq, _debug)
 
 
+def _flag_numpy_pipelined(torch, lib, p, vis, flags, average_freq):
+    """One numpy block, pipelined INSIDE the call (the dask graph hands over one block per call and thread,
+    dask_wrappers.py:23-46 of the reference): the block is cut into pieces along the baseline axis, piece i + 1 is
+    on the PCIe link while piece i's kernels run (two per-thread side streams, each with its own workspace),
+    and piece i's flags come back -- and are copied into the result array by the CPU -- under piece i + 1's
+    kernels.  Windows are independent (flagging.py:765-774), so the pieces' results are the block's results."""
+    nbl, ncorr, ntime, nchan = (int(x) for x in vis.shape)
+    device = torch.device("cuda", torch.cuda.current_device())
+    pieces = max(2, min(_PIPELINE_PIECES, nbl, (nbl * ncorr) // _PIPELINE_MIN_WINDOWS))
+    bounds = [nbl * k // pieces for k in range(pieces + 1)]
+    streams = getattr(_tls, "pipe_streams", None)
+    if streams is None:
+        streams = _tls.pipe_streams = {}
+    if device.index not in streams:
+        streams[device.index] = (torch.cuda.Stream(device), torch.cuda.Stream(device))
+    pair = streams[device.index]
+    caller = torch.cuda.current_stream(device)
+    res = _new_result(torch, (nbl, ncorr, ntime, nchan))
+    pending = None
+
+    def drain(item):
+        out, st, b0, b1 = item
+        with torch.cuda.stream(st):
+            _result_to_numpy(torch, out, device, res[b0:b1])
+    for k in range(pieces):
+        b0, b1 = bounds[k], bounds[k + 1]
+        if b1 <= b0:
+            continue
+        st = pair[k & 1]
+        st.wait_stream(caller)
+        with torch.cuda.stream(st):
+            out, _ = _flag_device(torch, lib, p, vis[b0:b1], flags[b0:b1], average_freq, None)
+        if pending is not None:
+            drain(pending)          # (its kernels were queued before this piece's copy: they ran under it)
+        pending = (out, st, b0, b1)
+    if pending is not None:
+        drain(pending)
+    return res
+
+
 def _flag_on_current_stream(torch, lib, p, vis, flags, average_freq, _debug):
+    out, from_numpy = _flag_device(torch, lib, p, vis, flags, average_freq, _debug)
+    if from_numpy:
+        return _result_to_numpy(torch, out, out.device)
+    return out
+
+
+def _flag_device(torch, lib, p, vis, flags, average_freq, _debug):
+    """Inputs to the device (if they are not there), the flagger on the current stream; returns the device
+    bool tensor and whether the caller handed over numpy arrays."""
     nbl, ncorr, ntime, nchan = (int(s) for s in vis.shape)
     v, f8, code, from_numpy, device = _as_device_inputs(torch, vis, flags)
     if code in (-64, -128):
@@ -357,33 +440,71 @@ def _flag_on_current_stream(torch, lib, p, vis, flags, average_freq, _debug):
             _lib.check(lib.tri_sum_threshold_flagger(
                 v.data_ptr(), code, f8.data_ptr(), out.data_ptr(), n_cp, ntime, nchan,
                 C.byref(p), None, 0, None))
-    out = out.view(torch.bool)
-    if from_numpy:
-        if _LINK_TURNS:
-            t0 = time.time()
-            torch.cuda.current_stream(device).synchronize()     # kernels done before queueing for the link
-            t1 = time.time()
-            # The result goes to a fresh numpy array, whose pages the kernel has to zero and map first:
-            # copied into directly, that happens page by page INSIDE the device-to-host copy (5-10 GB/s, and
-            # it drags down a concurrent host-to-device copy of another thread).  So: device -> this thread's
-            # pinned staging buffer at the link rate (5 ms for a 16-baseline block), link released, then a
-            # plain CPU copy into the fresh array.
-            stage = _d2h_stage(torch, out.numel())
-            if stage is None:
-                with _D2H_TURN:
-                    return out.cpu().numpy()
+    return out.view(torch.bool), from_numpy
+
+
+def _new_result(torch, shape):
+    """The numpy bool array a host call returns: ordinary memory, or (TRICOLOUR_AMD_PINNED_RESULTS=1) a view of a pinned
+    tensor from torch's caching host allocator (the array keeps the tensor alive; its memory returns to the pool with it)."""
+    if _PINNED_RESULTS:
+        try:
+            return torch.empty(shape, dtype=torch.bool, pin_memory=True).numpy()
+        except RuntimeError:
+            pass
+    return np.empty(shape, np.bool_)
+
+
+def _dest_is_pinned(torch, dest):
+    try:
+        return _PINNED_RESULTS and dest is not None and torch.from_numpy(dest).is_pinned()
+    except Exception:
+        return False
+
+
+def _result_to_numpy(torch, out, device, dest=None):
+    """Device flags of a numpy call -> a fresh numpy bool array, or the C-contiguous array `dest` (on the current stream)."""
+    shape = tuple(int(x) for x in out.shape)
+    if _PINNED_RESULTS:
+        if dest is None:
+            dest = _new_result(torch, shape)
+        if _dest_is_pinned(torch, dest):
+            torch.cuda.current_stream(device).synchronize()
             with _D2H_TURN:
-                t2 = time.time()
-                stage[:out.numel()].copy_(out.view(torch.uint8).reshape(-1), non_blocking=True)
+                torch.from_numpy(dest).copy_(out, non_blocking=True)
                 torch.cuda.current_stream(device).synchronize()
-            t3 = time.time()
-            res = np.empty((nbl, ncorr, ntime, nchan), np.bool_)
-            np.copyto(res.reshape(-1).view(np.uint8), stage[:out.numel()].numpy())
-            if _TRACE is not None:
-                _TRACE.append((threading.get_ident(), "kernels+d2h", t0, t1, t2, t3, time.time()))
-            return res
-        return out.cpu().numpy()
-    return out
+            return dest
+    if _LINK_TURNS:
+        t0 = time.time()
+        torch.cuda.current_stream(device).synchronize()     # kernels done before queueing for the link
+        t1 = time.time()
+        # The result goes to a fresh numpy array, whose pages the kernel has to zero and map first:
+        # copied into directly, that happens page by page INSIDE the device-to-host copy (5-10 GB/s, and
+        # it drags down a concurrent host-to-device copy of another thread).  So: device -> this thread's
+        # pinned staging buffer at the link rate (5 ms for a 16-baseline block), link released, then a
+        # plain CPU copy into the fresh array.
+        stage = _d2h_stage(torch, out.numel())
+        if stage is None:
+            with _D2H_TURN:
+                got = out.cpu().numpy()
+            if dest is None:
+                return got
+            np.copyto(dest, got)
+            return dest
+        with _D2H_TURN:
+            t2 = time.time()
+            stage[:out.numel()].copy_(out.view(torch.uint8).reshape(-1), non_blocking=True)
+            torch.cuda.current_stream(device).synchronize()
+        t3 = time.time()
+        res = np.empty(shape, np.bool_) if dest is None else dest
+        np.copyto(res.reshape(-1).view(np.uint8), stage[:out.numel()].numpy())
+        if _TRACE is not None:
+            _TRACE.append((threading.get_ident(), "kernels+d2h", t0, t1, t2, t3, time.time()))
+        return res
+    got = out.cpu().numpy()
+    if dest is None:
+        return got
+    np.copyto(dest, got)
+    return dest
 
 
 # ---------------------------------------------------------------------------
