@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turns two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs of `bench.py --roofline-only`)
-into the per-kernel traffic files bench.py reads: profiles/r02_pmc_<name>.json.
+into the per-kernel traffic files bench.py reads: profiles/r03_pmc_<name>.json.
 usage: pmc_roofline.py <fetch dir> <write dir> <bench json line file> <out dir>"""
 import collections, csv, glob, json, os, sys
 
@@ -14,7 +14,7 @@ def load(d, counter):
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 line = [l for l in open(sys.argv[3]) if l.startswith("{")][-1]
-roof = json.loads(line)["roofline"]
+roof = json.loads(line)["roofline_kernels"]
 out = sys.argv[4]
 
 def kb(per, pat, nth_largest_grid=0):
@@ -47,7 +47,7 @@ def emit(name, entry, pats, note):
          "traffic_over_algorithmic": hbm / entry["algorithmic_bytes_per_launch"],
          "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two separate passes, scripts/pmc_any.sh) -- python3 bench.py --roofline-only",
          "note": note}
-    json.dump(d, open(os.path.join(out, "r02_pmc_%s.json" % name), "w"), indent=1)
+    json.dump(d, open(os.path.join(out, "r03_pmc_%s.json" % name), "w"), indent=1)
     print(name, "traffic/algorithmic = %.3f" % d["traffic_over_algorithmic"])
 
 for e in roof:

@@ -1184,6 +1184,35 @@ int spectrum_background(const Run& r) {
         bool final_pass = ext == 0;
         double sigma = (double)(final_pass ? 1 : ext) * r.p->spike_width_freq;  // flagging.py:554, 576
         int rad = (int)box_radius(sigma);
+        // Radii beyond the stage pipeline (K4p): the spectra as ROWS through the exact row filter (K4x) -- the in-place
+        // multi-pass kernel walks 4 x (Fa + 4 r) positions with one wave per 64 windows: 5.8 ms per launch whatever
+        // the batch.  The 2-D time-stage scratch (ws.Aw ...) is idle here and holds the four row images.
+        const int xl = (rad > 0 && 2 * (size_t)pl.PT >= 4) ? boxx_pick_l(rad, Fa) : 0;
+        if (xl > 0) {
+            float* rowW = ws.Aw;                       // [Wn][Fa] weight rows, then the signed residual (unused)
+            float* rowO = ws.Aw + nS;                  // weight * data rows
+            float* rowD = ws.Aw + 2 * nS;              // the spectra themselves
+            float* rowR = ws.Aw + 3 * nS;              // result rows
+            hipLaunchKernelGGL(k_build_wo, grid1(nS, 1), dim3(256), 0, r.st, ws.sdata, ws.sbgf, ws.sw, ws.so, nS, (size_t)0, (size_t)0);
+            LAUNCHCHK();
+            int rc = launch_transpose<float>(r, ws.sw, rowW, Fa, Wn, 0, 0, 1);
+            if (!rc) rc = launch_transpose<float>(r, ws.so, rowO, Fa, Wn, 0, 0, 1);
+            if (!rc && ext == pl.nit) rc = launch_transpose<float>(r, ws.sdata, rowD, Fa, Wn, 0, 0, 1);
+            if (rc) return rc;
+            if (final_pass)
+                rc = launch_boxx<2>(r, xl, rowW, rowO, rowD, nullptr, rowR, rowW, Fa, Wn, Fa, rad, 0, 0, 0, 0, 0, 1, reinterpret_cast<uint8_t*>(ws.rowcnt));
+            else
+                rc = launch_boxx<1>(r, xl, rowW, rowO, rowD, nullptr, rowR, nullptr, Fa, Wn, Fa, rad, 0, 0, 0, 0, 0, 1, nullptr);
+            if (!rc) rc = launch_transpose<float>(r, rowR, ws.so, Wn, Fa, 0, 0, 1);
+            if (rc) return rc;
+            if (!final_pass) {
+                rc = spectrum_medians(r, ws.so, ws.sbgf);
+                if (rc) return rc;
+                hipLaunchKernelGGL(k_reject<false>, grid1(nS, 1), dim3(256), 0, r.st, ws.so, ws.sbgf, ws.smed, ws.d_chunk_of, rej, Fa, Wn, G, (size_t)0, (size_t)0);
+                LAUNCHCHK();
+            }
+            continue;
+        }
         if (rad > 0) {
             int rc = launch_colfilter(r, 0, ws.sw, ws.so, ws.sdata, ws.sbgf, ws.sw, ws.so, Fa, Wn, rad, 0, 0, 0, 1, nullptr, false, true);
             if (rc) return rc;
