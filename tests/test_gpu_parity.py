@@ -931,7 +931,10 @@ bad = 0
 for shape, kw in (((2, 1, 64, 128), dict(num_major_iterations=2)),
                   ((1, 2, 100, 144), dict(num_major_iterations=2, background_iterations=2, spike_width_time=20.0,
                                           spike_width_freq=15.0)),
-                  ((1, 1, 52, 300), dict(num_major_iterations=1, windows_freq=[1, 2, 4, 8, 16]))):
+                  ((1, 1, 52, 300), dict(num_major_iterations=1, windows_freq=[1, 2, 4, 8, 16])),
+                  # frequency radii 110 / 55: the exact row filter K4x (short chunks; long chunks on the 2048-channel lines)
+                  ((1, 2, 40, 512), dict(num_major_iterations=2, background_iterations=2, spike_width_freq=64.0)),
+                  ((1, 1, 16, 2048), dict(num_major_iterations=1, background_iterations=2, spike_width_freq=64.0))):
     vis = (rs.standard_normal(shape) + 1j * rs.standard_normal(shape)).astype(np.complex64)
     vis[..., shape[3] // 3] *= 8
     vis[:, :, shape[2] // 2, :] += 5
@@ -947,7 +950,8 @@ print("DIFF", bad)
 @pytest.mark.parametrize("knob", ["TRI_NO_AMPL_CACHE", "TRI_FILTER_NO_FUSED_DIV", "TRI_FILTER_NO_TIN", "TRI_FILTER_NO_LANE4",
                                   "TRI_NO_PACKED_FLAGS", "TRI_FILTER_MULTIPASS", "TRI_ST_GENERIC", "TRI_ST_REGISTER",
                                   "TRI_FILTER_DIRECT_FT", "TRI_FILTER_NO_REGRING", "TRI_FILTER_NO_REGRING_F", "TRI_MEDIAN_3PASS",
-                                  "TRI_NO_FUSED_REJECT", "TRI_NO_FT_SPEC_OR", "TRI_NO_FUSED_BEGIN", "TRI_NO_FUSED_DILATE", "TRI_SPEC_NO_PIPE", "TRI_INTERP_ONE_PASS", "TRI_MEDIAN_NO_PREDICT", "TRI_FILTER_NO_PIPE_T", "TRI_FILTER_NO_PIPE_F", "TRI_ST_NO_PIPE"])
+                                  "TRI_NO_FUSED_REJECT", "TRI_NO_FT_SPEC_OR", "TRI_NO_FUSED_BEGIN", "TRI_NO_FUSED_DILATE", "TRI_SPEC_NO_PIPE", "TRI_INTERP_ONE_PASS", "TRI_MEDIAN_NO_PREDICT", "TRI_FILTER_NO_PIPE_T", "TRI_FILTER_NO_PIPE_F", "TRI_ST_NO_PIPE",
+                                  "TRI_FILTER_NO_EXACT", "TRI_BOXX_NTI=256", "DEFAULT_ROUTES"])
 def test_alternate_kernel_paths(gpu, knob):
     """Every fallback / A-B path selectable through an environment knob (read once
     per process, hence the subprocess) stays bit-exact against the oracle."""
@@ -955,7 +959,8 @@ def test_alternate_kernel_paths(gpu, knob):
     import sys
     from conftest import ROOT
     env = dict(os.environ)
-    env[knob] = "1"
+    name, _, value = knob.partition("=")
+    env[name] = value or "1"
     p = subprocess.run([sys.executable, "-c", ALT_PATH_SCRIPT % ROOT], capture_output=True, text=True, env=env, timeout=600)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "DIFF 0" in p.stdout, p.stdout + p.stderr
