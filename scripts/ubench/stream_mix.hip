@@ -18,7 +18,7 @@
 #include <cstdint>
 #define L 1024
 #define C 4096
-enum { COPY4, LIN1, LIN4, LIN16, ROW16, ROWBITS, RD_ONLY, WR16_ONLY, LIN16_RD, LIN16_WR, PANEL64, PANEL256, PANEL256_WR, PANEL256_RD, ROW1 };
+enum { COPY4, LIN1, LIN4, LIN16, ROW16, ROWBITS, RD_ONLY, WR16_ONLY, LIN16_RD, LIN16_WR, PANEL64, PANEL256, PANEL256_WR, PANEL256_RD, ROW1, WRF_ROW256, WRF_ROW1K, WRF_PANEL64, WRF_LIN };
 template <int MODE>
 __global__ void __launch_bounds__(256) k(const float* __restrict__ in, uint8_t* __restrict__ out, float* __restrict__ out4, size_t n) {
     if (MODE == COPY4) {
@@ -92,6 +92,24 @@ __global__ void __launch_bounds__(256) k(const float* __restrict__ in, uint8_t* 
             }
         }
         if (MODE == PANEL256_RD && acc == 12345.f) o[0] = 1;
+    } else if (MODE == WRF_ROW256 || MODE == WRF_ROW1K || MODE == WRF_PANEL64) {
+        // float image writes only (what a time-axis filter stage does to its output images): per wave and row
+        // 256 B (one dword per lane), 1 KB (one float4 per lane), or 256 B into a [C/64][L][64] panel image
+        const size_t win = blockIdx.y;
+        float* o = out4 + win * (size_t)L * C;
+        if (MODE == WRF_ROW1K) {
+            const int c4 = blockIdx.x * 1024 + threadIdx.x * 4;          // (grid.x = C / 1024)
+            for (int t = 0; t < L; t++) *reinterpret_cast<float4*>(o + (size_t)t * C + c4) = make_float4((float)t, 1.f, 2.f, 3.f);
+        } else {
+            const int c = blockIdx.x * 256 + threadIdx.x;
+            const size_t base = MODE == WRF_PANEL64 ? (size_t)(c / 64) * L * 64 + (c % 64) : (size_t)c;
+            const size_t rs = MODE == WRF_PANEL64 ? 64 : C;
+            for (int t = 0; t < L; t++) o[base + (size_t)t * rs] = (float)t;
+        }
+    } else if (MODE == WRF_LIN) {
+        const size_t n4 = n / 4, stride = (size_t)gridDim.x * 256;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
+            reinterpret_cast<float4*>(out4)[i] = make_float4((float)i, 1.f, 2.f, 3.f);
     } else if (MODE == ROW1) {
         const size_t win = blockIdx.y;
         const float* p = in + win * (size_t)L * C;
@@ -145,8 +163,8 @@ void run(const char* name, const float* in, uint8_t* out, float* out4, int W, do
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const size_t n = (size_t)W * L * C;
-    const bool rows = MODE == ROW16 || MODE == ROWBITS || MODE == RD_ONLY || MODE == WR16_ONLY || MODE >= PANEL64;
-    dim3 grid = rows ? dim3(C / 256, W) : dim3(256 * 32, 1);
+    const bool rows = (MODE == ROW16 || MODE == ROWBITS || MODE == RD_ONLY || MODE == WR16_ONLY || MODE >= PANEL64) && MODE != WRF_LIN;
+    dim3 grid = rows ? dim3(MODE == WRF_ROW1K ? C / 1024 : C / 256, W) : dim3(256 * 32, 1);
     k<MODE><<<grid, 256>>>(in, out, out4, n);
     hipEventRecord(e0);
     for (int i = 0; i < 5; i++) k<MODE><<<grid, 256>>>(in, out, out4, n);
@@ -178,5 +196,9 @@ int main() {
     run<PANEL256>("panel256: same walk over [C/256][L][256] panels (5 B)", in, out, out4, W, 5);
     run<PANEL256_RD>("panel256 reads only (4 B)", in, out, out4, W, 4);
     run<PANEL256_WR>("panel256 byte writes only (1 B)", in, out, out4, W, 1);
+    run<WRF_ROW256>("float writes only, row walk, 256 B per wave and row (4 B)", in, out, out4, W, 4);
+    run<WRF_ROW1K>("float writes only, row walk, 1 KB per wave and row (4 B)", in, out, out4, W, 4);
+    run<WRF_PANEL64>("float writes only, [C/64][L][64] panels, 256 B per wave and row (4 B)", in, out, out4, W, 4);
+    run<WRF_LIN>("float writes only, linear float4 (4 B)", in, out, out4, W, 4);
     return 0;
 }
