@@ -483,6 +483,9 @@ def main():
                     help="run only the per-kernel roofline legs (what the rocprofv3 --pmc passes of profiles/ wrap)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher rehearsal without a GPU: every rank joins a gloo group, rank 0 prints the rank count")
+    ap.add_argument("--dry-run-fail-rank", type=int, default=-1,
+                    help="launcher rehearsal: this rank leaves with exit code 3 the way a failed scatter leg does, while its "
+                         "peers wait in a collective -- the launcher must tear the group down and report a non-zero code")
     args = ap.parse_args()
 
     env_world = os.environ.get("WORLD_SIZE")
@@ -506,6 +509,13 @@ def main():
             t = torch.ones(1)
             dist.all_reduce(t)
             n = int(t.item())
+            if args.dry_run_fail_rank >= 0:
+                if rank == args.dry_run_fail_rank:
+                    if rank == 0:
+                        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_joined": n, "scatter": {"error": "rehearsed failure"}}))
+                        sys.stdout.flush()
+                    os._exit(3)
+                dist.barrier()                 # (never completes: the launcher ends this rank)
             dist.destroy_process_group()
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_joined": n}))

@@ -34,3 +34,13 @@ def test_gpus_world_size_mismatch_is_an_error():
 def test_single_rank_dry_run():
     p = _run(["--dry-run"])
     assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_failing_rank_reaches_the_caller_as_a_nonzero_exit():
+    """a rank that leaves the way a failed / stuck scatter leg does (exit code 3 after the line is flushed)
+    while its peer waits in a collective must end the whole launch with a non-zero code -- not hang, not report 0."""
+    for failing in (0, 1):
+        p = _run(["--gpus", "2", "--dry-run", "--dry-run-fail-rank", str(failing)], timeout=240)
+        assert p.returncode != 0, (failing, p.stdout[-500:], p.stderr[-500:])
+        if failing == 0:
+            assert '"scatter": {"error"' in p.stdout          # the headline line still came out

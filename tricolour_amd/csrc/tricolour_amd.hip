@@ -517,7 +517,10 @@ int boxr_pick_ks(int rad) {
 
 // the time-axis stage keeps K4b below 16 slots (already at the HBM floor there); the fused
 // frequency stage takes the register form from r = 4 on
-int boxr_pick_ks_t(int rad) { return 2 * rad >= 32 ? boxr_pick_ks(rad) : 0; }
+#ifndef BOXT_MIN_2R
+#define BOXT_MIN_2R 32
+#endif
+int boxr_pick_ks_t(int rad) { return 2 * rad >= BOXT_MIN_2R ? boxr_pick_ks(rad) : 0; }
 int boxr_pick_ks_f(int rad) {
     static const bool off = [] { const char* e = getenv("TRI_FILTER_NO_REGRING_F"); return e && e[0] == '1'; }();
     return off ? 0 : boxr_pick_ks(rad);
@@ -645,6 +648,7 @@ int launch_boxq(const Run& r, int ks, const float* srcData, const uint8_t* srcFl
 int launch_boxt(const Run& r, int ks, const float* srcData, const uint8_t* srcFlags, float* dstW, float* dstO,
                 int n, int C, int rad, float denom, size_t sws, size_t dws, int64_t W) {
     switch (ks) {
+        case 16: return launch_boxt_ks<16>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
         case 32: return launch_boxt_ks<32>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
         case 64: return launch_boxt_ks<64>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
         case 80: return launch_boxt_ks<80>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
