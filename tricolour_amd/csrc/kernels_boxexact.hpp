@@ -66,8 +66,8 @@ __host__ __device__ constexpr size_t boxx_lds_bytes(int NTI, int L, int r) {
 #endif
 template <int NTI, int L, int MODE, bool RECIP>
 __global__ void __launch_bounds__(2 * NTI, NTI == 256 ? BOXX_MINWAVES : BOXX_MINWAVES128)
-k_boxx(const float* __restrict__ srcW, unsigned img_gap, const float* __restrict__ data, const uint8_t* __restrict__ mask,
-       float* __restrict__ outA, float* __restrict__ outB, int n, int ld, int r, BoxDenom denom, size_t sws_img,
+k_boxx(const float* srcW, unsigned img_gap, const float* __restrict__ data, const uint8_t* __restrict__ mask,
+       float* outA, float* outB, int n, int ld, int r, BoxDenom denom, size_t sws_img,      // (outA / outB may alias the source rows: no __restrict__)
        size_t ws_data, size_t ws_mask, size_t ws_outA, size_t ws_outB, uint8_t* __restrict__ nanflag,
        unsigned long long* __restrict__ stats) {
     extern __shared__ float cf_ring[];
