@@ -190,8 +190,9 @@ def parity_check(torch, tricolour_amd, device, kw, vis, flags, expected, chain=N
     dv = torch.from_numpy(vis).to(device)
     df = torch.from_numpy(flags).to(device)
     if chain is not None:
-        f = tricolour_amd.flag_nans_and_zeros(dv, df)
-        f = tricolour_amd.uvcontsub_flagger(dv, f, **chain)
+        from tricolour_amd import flagging
+        f = flagging.flag_nans_and_zeros(dv, df)
+        f = flagging.uvcontsub_flagger(dv, f, **chain)
         got = tricolour_amd.sum_threshold_flagger(dv, f, **kw) | f
     else:
         got = tricolour_amd.sum_threshold_flagger(dv, df, **kw)

@@ -63,7 +63,7 @@ for e in roof:
     elif "frequency-axis" in k:
         rad = int(k.rsplit("r = ", 1)[1])
         if 34 <= 2 * rad < 112:
-            pat = "k_boxqf<%d, 1>" % (2 * rad // 16 * 16)
+            pat = "k_boxqf<%d, 1," % (2 * rad // 16 * 16)
         else:
             ks = 80 if 2 * rad >= 80 else 64 if 2 * rad >= 64 else 32 if 2 * rad >= 32 else 16 if 2 * rad >= 16 else 8
             pat = "k_boxf<%d, %s, 1," % (ks, "true" if 2 * rad > ks else "false")

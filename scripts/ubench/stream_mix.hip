@@ -18,7 +18,7 @@
 #include <cstdint>
 #define L 1024
 #define C 4096
-enum { COPY4, LIN1, LIN4, LIN16, ROW16, ROWBITS, RD_ONLY, WR16_ONLY, LIN16_RD, LIN16_WR, PANEL64, PANEL256, PANEL256_WR, PANEL256_RD, ROW1, WRF_ROW256, WRF_ROW1K, WRF_PANEL64, WRF_LIN };
+enum { COPY4, LIN1, LIN4, LIN16, ROW16, ROWBITS, RD_ONLY, WR16_ONLY, LIN16_RD, LIN16_WR, PANEL64, PANEL256, PANEL256_WR, PANEL256_RD, ROW1, WRF_ROW256, WRF_ROW1K, WRF_PANEL64, WRF_LIN, SEG64_RD };
 template <int MODE>
 __global__ void __launch_bounds__(256) k(const float* __restrict__ in, uint8_t* __restrict__ out, float* __restrict__ out4, size_t n) {
     if (MODE == COPY4) {
@@ -106,6 +106,24 @@ __global__ void __launch_bounds__(256) k(const float* __restrict__ in, uint8_t* 
             const size_t rs = MODE == WRF_PANEL64 ? 64 : C;
             for (int t = 0; t < L; t++) o[base + (size_t)t * rs] = (float)t;
         }
+    } else if (MODE == SEG64_RD) {
+        // the fused frequency stage's input shape: one float4 per lane, a wave instruction covers 16 rows x 64 bytes
+        // (lane = (row, quarter)); rows are image rows 16 KB apart, the walk goes along the row.  Reads only -- used
+        // under rocprofv3 --pmc FETCH_SIZE to calibrate the counter for this shape (known bytes: 4 per sample).
+        const size_t win = blockIdx.y;
+        const float* p = in + win * (size_t)L * C;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int row0 = (blockIdx.x * 4 + wave) * 16 + (lane >> 2);      // (grid.x = L / 64)
+        const float* src = p + (size_t)row0 * C + (lane & 3) * 4;
+        float acc = 0;
+        for (int f0 = 0; f0 < C; f0 += 16 * 4) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const float4*>(src + f0 + 16 * u);
+#pragma unroll
+            for (int u = 0; u < 4; u++) acc += v[u].x + v[u].y + v[u].z + v[u].w;
+        }
+        if (acc == 12345.f) out[threadIdx.x] = 1;
     } else if (MODE == WRF_LIN) {
         const size_t n4 = n / 4, stride = (size_t)gridDim.x * 256;
         for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
@@ -164,7 +182,7 @@ void run(const char* name, const float* in, uint8_t* out, float* out4, int W, do
     hipEventCreate(&e0); hipEventCreate(&e1);
     const size_t n = (size_t)W * L * C;
     const bool rows = (MODE == ROW16 || MODE == ROWBITS || MODE == RD_ONLY || MODE == WR16_ONLY || MODE >= PANEL64) && MODE != WRF_LIN;
-    dim3 grid = rows ? dim3(MODE == WRF_ROW1K ? C / 1024 : C / 256, W) : dim3(256 * 32, 1);
+    dim3 grid = MODE == SEG64_RD ? dim3(L / 64, W) : (rows ? dim3(MODE == WRF_ROW1K ? C / 1024 : C / 256, W) : dim3(256 * 32, 1));
     k<MODE><<<grid, 256>>>(in, out, out4, n);
     hipEventRecord(e0);
     for (int i = 0; i < 5; i++) k<MODE><<<grid, 256>>>(in, out, out4, n);
@@ -200,5 +218,6 @@ int main() {
     run<WRF_ROW1K>("float writes only, row walk, 1 KB per wave and row (4 B)", in, out, out4, W, 4);
     run<WRF_PANEL64>("float writes only, [C/64][L][64] panels, 256 B per wave and row (4 B)", in, out, out4, W, 4);
     run<WRF_LIN>("float writes only, linear float4 (4 B)", in, out, out4, W, 4);
+    run<SEG64_RD>("reads only, 64-byte row segments: float4 per lane, 16 rows per wave instruction (4 B)", in, out, out4, W, 4);
     return 0;
 }

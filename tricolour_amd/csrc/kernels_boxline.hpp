@@ -296,7 +296,15 @@ k_boxt_spec(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFl
 // The filtered images are never written.  Buffer addressing throughout (host: images and
 // outputs below 2^31 bytes per window).
 // grid (ceil(C / 32), W), block 64, dynamic LDS 4 * d * 64 + 2 * PF * 34 floats
-#define BOXF_TS 34                                             // tile row stride (floats): conflict-free column writes and row reads
+// tile row stride (floats): conflict-free column writes and row reads -- the staging writes go to rows s_pos (0 .. PF-1),
+// columns LPI j + s_line0: 34 spreads 16 positions x 2 lines over the 32 banks, 33 does it for 32 positions x 1 line
+__host__ __device__ constexpr int boxf_ts(int pf) { return pf >= 32 ? 33 : 34; }
+#define BOXF_TS 34
+// cache policy of the fused stage's streaming accesses (amplitudes in, results out: touched once): 0 = default;
+// 2 = non-temporal, so that they do not push the half-read input lines (64 of 128 bytes per block) out of L2
+#ifndef BOXF_STREAM_AUX
+#define BOXF_STREAM_AUX 0
+#endif
 template <int KS, bool HASL, int MODE, int WPS = boxr_waves_f(KS)>   // WPS: waves per SIMD the registers are budgeted for
 __global__ void __launch_bounds__(64, WPS)
 k_boxf(const float* __restrict__ srcW, unsigned img_gap,
@@ -308,7 +316,7 @@ k_boxf(const float* __restrict__ srcW, unsigned img_gap,
     constexpr int UNR = boxr_lcm(KS, PF);
     constexpr int BT = 64;
     constexpr int LPI = 32 / PF;                               // lines covered by one staging load instruction (per image)
-    constexpr int TS = BOXF_TS;
+    constexpr int TS = boxf_ts(PF);
     const int lane = threadIdx.x;
     const int half = lane >> 5;                                // 0: weight image, 1: data image
     const int hl = lane & 31;
@@ -380,7 +388,7 @@ k_boxf(const float* __restrict__ srcW, unsigned img_gap,
         if (fast) {
 #pragma unroll
             for (int k = 0; k < PF / 2; k++)
-                dpre[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, hoff, (int)((unsigned)(i0 + k) * rowb), 0));
+                dpre[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, hoff, (int)((unsigned)(i0 + k) * rowb), BOXF_STREAM_AUX));
         } else {
 #pragma unroll
             for (int k = 0; k < PF / 2; k++) {
@@ -456,10 +464,10 @@ k_boxf(const float* __restrict__ srcW, unsigned img_gap,
                                 const int vo = fast ? hoff : (c * 4 + (int)((unsigned)i * rowb));
                                 const int so = fast ? (int)((unsigned)(i0 + k) * rowb) : 0;
                                 if (MODE == 1) {
-                                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fabsf(dpre[k] - bg)), ors, vo, so, 0);
+                                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fabsf(dpre[k] - bg)), ors, vo, so, BOXF_STREAM_AUX);
                                 } else {
-                                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bg), ors, vo, so, 0);
-                                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dpre[k] - bg), wrs, vo, so, 0);
+                                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bg), ors, vo, so, BOXF_STREAM_AUX);
+                                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dpre[k] - bg), wrs, vo, so, BOXF_STREAM_AUX);
                                     line_nan |= isnan(bg);
                                 }
                             }
