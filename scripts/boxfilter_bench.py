@@ -13,6 +13,9 @@ ap.add_argument("--radii", default="8,10,17,21,32,43,54")
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--variants", default="1,2")
 ap.add_argument("--stage", type=int, default=0)
+ap.add_argument("--tiny-lines", type=float, default=0.0,
+                help="stage 1: this fraction of the lines gets one weight of 1e-30 -- their float64 sums are inexact, the exact row "
+                     "filter (variant 4) has to redo them in the reference's sequential order")
 ap.add_argument("--time-radius", type=int, default=28,
                 help="stage 1: its input images are the time-axis stage's outputs at this radius (as in the flagger)")
 a = ap.parse_args()
@@ -40,6 +43,12 @@ if a.stage == 1 and a.time_radius > 0:
     both[:, 0] = tw
     both[:, 1] = to
     del tw, to
+if a.stage == 1 and a.tiny_lines > 0:
+    pick = torch.rand((W, T), generator=g, device=dev) < a.tiny_lines
+    col = both[:, 0, :, 100]
+    col[pick] = 1e-30
+    both[:, 0, :, 100] = col
+    print("tiny weights on %d of %d lines" % (int(pick.sum().item()), W * T))
 ow = [torch.empty((W, T, F), device=dev) for _ in range(2)]
 oo = [torch.empty((W, T, F), device=dev) for _ in range(2)]
 ms = C.c_float(0)

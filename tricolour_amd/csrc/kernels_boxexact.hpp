@@ -41,7 +41,7 @@
 // Long chunks (NTI = 128) spend fewer instructions per line: the per-thread cost of gathering a window's chunk
 // totals and minima falls with a = (2r + 1) / L, the recurrence costs the same per position either way.
 // grid (C lines, W windows), block 2 NTI, dynamic LDS boxx_lds_bytes(NTI, L, r).
-// Host: n % 4 == 0, n + 4r <= NTI L, L <= 2r + 1, (2r + 1) / L <= BOXX_AMAX, 16-byte aligned rows.
+// Host: n % 4 == 0, n + 4r <= NTI L, L <= 2r + 1 (hence r >= 8), (2r + 1) / L <= BOXX_AMAX, 16-byte aligned rows.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -210,11 +210,52 @@ k_boxx(const float* srcW, unsigned img_gap, const float* __restrict__ data, cons
         } else {
             // the reference's own order, one thread per image, in place (flagging.py:398-416 with zeros added
             // where the reference skips them: s + 0.0 == s)
+            // (in batches of 16 positions, loads first and stores last: a load-add-store loop would pay the LDS
+            //  latency at every position -- 0.6 ms per pass; a batch never stores what it still has to load: 2r >= 16)
             if (l == 0) {
+                constexpr int SB = 16;
                 double s = 0.0;
-                for (int k = 0; k < R2 && k < P; k++) s += (double)X[k];
-                for (int i = 0; i < P; i++) {
-                    if (i + R2 < P) s += (double)X[i + R2];
+                const int pro = R2 < P ? R2 : P;               // prologue: the first 2r positions enter the sum
+                int k = 0;
+                for (; k + SB <= pro; k += SB) {
+                    float v[SB];
+#pragma unroll
+                    for (int u = 0; u < SB; u++) v[u] = X[k + u];
+#pragma unroll
+                    for (int u = 0; u < SB; u++) s += (double)v[u];
+                }
+                for (; k < pro; k++) s += (double)X[k];
+                const int lead_end = P - R2 > 0 ? P - R2 : 0;  // positions that still have a sample 2r ahead
+                int i = 0;
+                for (; i + SB <= lead_end; i += SB) {
+                    float lead[SB], prev[SB], o[SB];
+#pragma unroll
+                    for (int u = 0; u < SB; u++) { lead[u] = X[i + R2 + u]; prev[u] = X[i + u]; }
+#pragma unroll
+                    for (int u = 0; u < SB; u++) {
+                        s += (double)lead[u];
+                        o[u] = (float)s;
+                        s -= (double)prev[u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < SB; u++) X[i + u] = o[u];
+                }
+                for (; i < lead_end; i++) {
+                    s += (double)X[i + R2];
+                    const float prev = X[i];
+                    X[i] = (float)s;
+                    s -= (double)prev;
+                }
+                for (; i + SB <= P; i += SB) {                 // the tail: nothing left to add (flagging.py:412-416)
+                    float prev[SB], o[SB];
+#pragma unroll
+                    for (int u = 0; u < SB; u++) prev[u] = X[i + u];
+#pragma unroll
+                    for (int u = 0; u < SB; u++) { o[u] = (float)s; s -= (double)prev[u]; }
+#pragma unroll
+                    for (int u = 0; u < SB; u++) X[i + u] = o[u];
+                }
+                for (; i < P; i++) {
                     const float prev = X[i];
                     X[i] = (float)s;
                     s -= (double)prev;
