@@ -282,6 +282,48 @@ def test_exact_row_filter_vs_oracle(gpu, oracle, shape, radius):
     assert passes == 4 * 2 * w * t and 0 < seq <= 4 * 2 * w * 6, (passes, seq)
 
 
+def test_exact_row_filter_random_stress(gpu, oracle):
+    """Seeded sweep over line lengths, radii and dynamic ranges that straddle the exactness boundary of K4x (2^28 between a
+    window's total and its smallest term): whichever lines and passes take the sequential redo, the result must equal the
+    oracle's sequential filter bit for bit.  Also: zero bands of random width, tiny values at the line ends only (where the
+    padded tail votes or not), lines of constant value."""
+    import ctypes as C
+    from tricolour_amd import _lib
+    rs = np.random.RandomState(2024)
+    ran = redo = 0
+    for case in range(48):
+        f = int(rs.choice([64, 128, 260, 512, 1000, 2048, 4096]))
+        r = int(rs.choice([8, 9, 13, 21, 33, 55, 56, 80, 110, 166, 277]))
+        t = 8
+        shape = (1, t, f)
+        spread = rs.choice([0.5, 4.0, 9.0, 12.0])                     # decades of dynamic range
+        wimg = (rs.uniform(size=shape) * 0.45 + 0.5).astype(np.float32)
+        oimg = (wimg * (10.0 ** rs.uniform(-spread / 2, spread / 2, size=shape))).astype(np.float32)
+        z0 = int(rs.randint(0, f))
+        zw = int(rs.randint(0, max(1, f // 2)))
+        wimg[:, 2, z0:z0 + zw] = 0.0
+        oimg[:, 2, z0:z0 + zw] = 0.0
+        if case % 2:
+            oimg[:, 3, :3] = np.float32(1e-25)                       # tiny at the start only
+            oimg[:, 4, -3:] = np.float32(1e-25)                      # tiny at the end only (the tail of the padded line)
+        oimg[:, 5, :] = np.float32(3.25)
+        wimg[:, 5, :] = np.float32(1.0)
+        data = (rs.standard_normal((1, f, t)) * 3 + 10).astype(np.float32)
+        both = np.ascontiguousarray(np.stack([wimg, oimg], axis=1), np.float32)
+        try:
+            got = _freq_stage(wimg, oimg, data, r, 4)
+        except NotImplementedError:
+            continue                                                 # no chunk length for this (line, radius)
+        exp = _freq_stage_expected(oracle, wimg, oimg, data, r)
+        ok = _same_f32(exp, got)
+        assert ok.all(), "case %d (f = %d, r = %d, spread 10^%.1f): %d of %d words differ (first at %s)" % (
+            case, f, r, spread, (~ok).sum(), ok.size, np.argwhere(~ok)[0])
+        ran += 1
+        redo += _boxx_stats()[1] > 0
+    assert ran >= 30 and 0 < redo, (ran, redo)
+    print("exact row filter stress: %d cases, %d with at least one pass redone sequentially" % (ran, redo))
+
+
 def test_random_windows_multi_batch(gpu, oracle):
     """Several windows, tiny workspace budget -> several internal batches."""
     import os
