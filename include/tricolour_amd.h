@@ -43,7 +43,12 @@ enum tri_status {
 enum tri_vis_dtype {
     TRI_VIS_C64 = 0,     /* interleaved (re, im) float32 -- MS DATA columns     */
     TRI_VIS_F32 = 1,     /* real float32 amplitudes (flagging.py:830-832)       */
-    TRI_VIS_C128 = 2     /* interleaved float64: tri_stokes_intensity only       */
+    TRI_VIS_C128 = 2,    /* interleaved float64: tri_stokes_intensity only       */
+    TRI_VIS_F64 = 3      /* real float64 AMPLITUDES: what float64 / complex128 visibilities are to
+                            _average_freq (np.abs in float64, flagging.py:856), added to the float32
+                            accumulator in float64 and rounded at every step (:858-859).  The caller forms
+                            them (|x|, hypot(re, im)); a visibility with a NaN part must arrive as NaN
+                            (the final isnan(in_data), :777-781).  tri_sum_threshold_flagger only.      */
 };
 
 /*

@@ -153,13 +153,17 @@ def sum_threshold_flagger(vis, flags, n_threads=1, dump=False, **kw):
     flags8 = np.ascontiguousarray(flags != 0).view(np.uint8)
     p, fa = make_params(T, F, **kw)
     out = np.zeros(vis.shape, np.uint8)
-    c64 = f32 = None
+    c64 = f32 = c128 = f64 = None
     if vis.dtype == np.complex64:
         c64 = vis
     elif vis.dtype == np.float32:
         f32 = vis
+    elif vis.dtype == np.complex128:
+        c128 = vis
+    elif vis.dtype == np.float64:
+        f64 = vis
     else:
-        raise TypeError("oracle handles complex64 / float32 visibilities")
+        raise TypeError("oracle handles real / complex float32 / float64 visibilities")
     dptr = fptr = None
     d = {}
     if dump:
@@ -171,9 +175,9 @@ def sum_threshold_flagger(vis, flags, n_threads=1, dump=False, **kw):
                  freq_flags=np.zeros((T, fa), np.uint8))
         dptr = (C.c_void_p * 3)(_p(d["spec_resid"]), _p(d["background"]), _p(d["residual"]))
         fptr = (C.c_void_p * 3)(_p(d["spec_flags"]), _p(d["time_flags"]), _p(d["freq_flags"]))
-    lib().tro_sum_threshold_flagger(_p(c64), _p(f32), _p(flags8), _p(out),
-                                    _i64(nbl * ncorr), _i64(T), _i64(F),
-                                    C.byref(p), C.c_int(n_threads), dptr, fptr)
+    lib().tro_sum_threshold_flagger_any(_p(c64), _p(f32), _p(c128), _p(f64), _p(flags8), _p(out),
+                                        _i64(nbl * ncorr), _i64(T), _i64(F),
+                                        C.byref(p), C.c_int(n_threads), dptr, fptr)
     out = out.view(np.bool_)
     return (out, d) if dump else out
 

@@ -48,4 +48,4 @@ def load_golden(name):
 
 GOLDEN_CASES = ["G1_defaults.npz", "G2_stage1.npz", "G2b_radius32.npz", "G3_broad.npz",
                 "G4_preflagged.npz", "G5_complex_nan.npz", "G6_all_flagged.npz",
-                "G7_clipping.npz", "G10_average2.npz"]
+                "G7_clipping.npz", "G10_average2.npz", "G14_wide_average3.npz", "G14b_complex128_average3.npz"]

@@ -221,6 +221,25 @@ def main(names):
         out, inter = run_reference(fl, vis, flags, **kw)
         save("G10_average2", vis, flags, kw, out, inter, t0)
 
+    if todo("G14"):
+        # float64 / complex128 input WITH channel averaging: abs in float64, and `avg_data[...] += data` adds a float64 to a
+        # float32 element -- rounded to float32 at every step (flagging.py:856-859).  Amplitudes carry bits below float32
+        # precision so that this differs from rounding first; the complex samples have one zero component (|z| exact).
+        t0 = time.time(); rs = np.random.RandomState(14)
+        amp = synth(rs, (1, 2, 40, 101)).astype(np.float64) * (1.0 + 1e-9 * rs.standard_normal((1, 2, 40, 101)))
+        flags = np.zeros(amp.shape, np.bool_); flags[..., 33:36] = True; flags[0, 1, 7, :] = True
+        amp[0, 0, 3, 50] = np.nan
+        kw = dict(average_freq=3, windows_freq=[3, 6, 12, 24], freq_chunks=4,
+                  num_major_iterations=2, freq_extend=5)
+        out, inter = run_reference(fl, amp, flags, **kw)
+        save("G14_wide_average3", amp, flags, kw, out, inter, t0)
+        pick = rs.uniform(size=amp.shape) < 0.5
+        z = np.where(pick, amp + 0j, 1j * amp).astype(np.complex128)
+        z[0, 1, 9, 13] = complex(np.inf, np.nan)
+        flags2 = flags.copy(); flags2[0, 1, 9, 13] = True
+        out, inter = run_reference(fl, z, flags2, **kw)
+        save("G14b_complex128_average3", z, flags2, kw, out, inter, t0)
+
 
 if __name__ == "__main__":
     main(sys.argv[1:])

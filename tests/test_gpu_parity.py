@@ -909,6 +909,39 @@ def test_flag_dtypes_and_non_contiguous_inputs(gpu, oracle):
         gpu.sum_threshold_flagger(vis.real.astype(np.int32), flags, **kw)
 
 
+def test_wide_input_types_with_channel_averaging(gpu, oracle):
+    """float64 / complex128 visibilities with average_freq > 1 (missing item 5; flagging.py:856-859): the
+    float64 amplitude is added to the float32 accumulator in float64 and rounded at every step -- not the same as
+    rounding the amplitude first.  Against the oracle, whose wide path is pinned bit for bit by the reference-generated
+    fixtures G14 / G14b (tests/test_oracle_golden.py); numpy and device inputs; NaN parts and pre-flagged infinities."""
+    import torch
+    rs = np.random.RandomState(41)
+    shape = (2, 2, 36, 90)
+    for avg, wf in ((2, [2, 4, 8, 16]), (3, [3, 6, 12]), (4, [4, 8, 16])):
+        amp = (np.abs(rs.standard_normal(shape) * 0.7 + 5.0) * (1.0 + 1e-9 * rs.standard_normal(shape))).astype(np.float64)
+        amp[..., 30] += 6.0
+        amp[0, 1, 9, :] += 4.0
+        flags = rs.uniform(size=shape) < 0.04
+        amp[1, 0, 5, 7] = np.nan
+        kw = dict(average_freq=avg, windows_freq=wf, freq_chunks=3, num_major_iterations=2, freq_extend=avg + 2)
+        exp = oracle.sum_threshold_flagger(amp, flags, **kw)
+        assert np.array_equal(gpu.sum_threshold_flagger(amp, flags, **kw), exp), avg
+        got = gpu.sum_threshold_flagger(torch.from_numpy(amp).cuda(), torch.from_numpy(flags).cuda(), **kw)
+        assert np.array_equal(got.cpu().numpy(), exp), avg
+        # the same amplitudes split over real / imaginary parts (one part zero: |z| is exact in any hypot)
+        z = np.where(rs.uniform(size=shape) < 0.5, amp + 0j, 1j * amp).astype(np.complex128)
+        z[0, 0, 3, 11] = complex(np.inf, np.nan)
+        f2 = flags.copy()
+        f2[0, 0, 3, 11] = True
+        expz = oracle.sum_threshold_flagger(z, f2, **kw)
+        assert expz[0, 0, 3, 11]
+        assert np.array_equal(gpu.sum_threshold_flagger(z, f2, **kw), expz), avg
+    # float32-rounded amplitudes give a different answer on some sample of such data: the float64 path is not a no-op
+    sums32 = (amp.astype(np.float32)[..., 0::2] + amp.astype(np.float32)[..., 1::2])
+    sums64 = (amp[..., 0::2] + amp[..., 1::2]).astype(np.float32)
+    assert (sums32 != sums64).any()
+
+
 def _random_case(rs):
     """A random small window set + kwargs inside the reference's contract."""
     T = int(rs.choice([1, 2, 5, 16, 31, 48, 64, 100, 130, 257, 300]))

@@ -31,7 +31,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17",
                "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 
 TRI_OK, TRI_EINVAL, TRI_EUNSUPPORTED, TRI_EWORKSPACE, TRI_EHIP = range(5)
-TRI_VIS_C64, TRI_VIS_F32, TRI_VIS_C128 = 0, 1, 2
+TRI_VIS_C64, TRI_VIS_F32, TRI_VIS_C128, TRI_VIS_F64 = 0, 1, 2, 3
 TRI_MAX_WINDOWS = 16
 
 

@@ -148,7 +148,10 @@ __host__ __device__ constexpr int boxr_waves(int ks) { return ks <= 16 ? BOXR_WA
 #define BOXF_PF_SMALL 16
 #endif
 __host__ __device__ constexpr int boxr_pf_f(int ks) { return ks <= 16 ? BOXF_PF_SMALL : boxr_pf(ks); }
-__host__ __device__ constexpr int boxr_waves_f(int ks) { return ks < 32 ? 2 : (ks == 32 ? BOXR_WAVES_F32 : 1); }
+#ifndef BOXR_WAVES_F16
+#define BOXR_WAVES_F16 2
+#endif
+__host__ __device__ constexpr int boxr_waves_f(int ks) { return ks < 32 ? BOXR_WAVES_F16 : (ks == 32 ? BOXR_WAVES_F32 : 1); }
 __host__ __device__ constexpr int boxr_lcm(int a, int b) {
     int x = a, y = b;
     while (y) { int t = x % y; x = y; y = t; }

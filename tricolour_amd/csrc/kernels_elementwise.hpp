@@ -23,6 +23,12 @@ __global__ void k_prepare(const void* __restrict__ vis, const uint8_t* __restric
     float sum = 0.0f;
     int cnt = 0;
     for (int f = f0; f < f1; f++) {
+        if (VD == TRI_VIS_F64) {
+            // float64 amplitude + float32 accumulator: the sum is formed in float64 and stored as float32 (flagging.py:858-859)
+            const double a = fabs(reinterpret_cast<const double*>(vis)[base + f]);
+            if (!iflags[base + f] && !isnan(a)) { sum = (float)((double)sum + a); cnt++; }
+            continue;
+        }
         float a = load_amp<VD>(vis, base + f);
         if (!iflags[base + f] && !isnan(a)) { sum += a; cnt++; }
     }

@@ -85,6 +85,8 @@ __device__ __forceinline__ float load_amp(const void* vis, size_t i) {
     if (VD == TRI_VIS_C64) {
         float2 z = reinterpret_cast<const float2*>(vis)[i];
         return tri_hypotf(z.x, z.y);
+    } else if (VD == TRI_VIS_F64) {
+        return (float)fabs(reinterpret_cast<const double*>(vis)[i]);   // (k_prepare accumulates the float64 value itself)
     } else {
         return fabsf(reinterpret_cast<const float*>(vis)[i]);
     }
@@ -95,6 +97,8 @@ __device__ __forceinline__ bool load_isnan(const void* vis, size_t i) {
     if (VD == TRI_VIS_C64) {
         float2 z = reinterpret_cast<const float2*>(vis)[i];
         return isnan(z.x) || isnan(z.y);
+    } else if (VD == TRI_VIS_F64) {
+        return isnan(reinterpret_cast<const double*>(vis)[i]);
     } else {
         return isnan(reinterpret_cast<const float*>(vis)[i]);
     }

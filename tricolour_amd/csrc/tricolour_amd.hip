@@ -1636,7 +1636,7 @@ int process_windows(Run& r, const void* vis, int vis_dtype, const uint8_t* flags
         LAUNCHCHK();
     }
     const size_t NF = (size_t)T * F;
-    const size_t esz = vis_dtype == TRI_VIS_C64 ? 8 : 4;
+    const size_t esz = (vis_dtype == TRI_VIS_C64 || vis_dtype == TRI_VIS_F64) ? 8 : 4;
     int rc = TRI_OK;
     for (int64_t w0 = w_begin; w0 < w_end; w0 += Wb) {
         r.Wb = std::min(Wb, w_end - w0);
@@ -1663,6 +1663,7 @@ int process_windows(Run& r, const void* vis, int vis_dtype, const uint8_t* flags
             bool last = it == p->num_major_iterations - 1;
             bool tap = last && tap_first && w0 == w_begin;
             if (vis_dtype == TRI_VIS_C64) rc = run_iteration<TRI_VIS_C64>(r, vis_b, r.ws.iter, out_b, !last, tap);
+            else if (vis_dtype == TRI_VIS_F64) rc = run_iteration<TRI_VIS_F64>(r, vis_b, r.ws.iter, out_b, !last, tap);
             else rc = run_iteration<TRI_VIS_F32>(r, vis_b, r.ws.iter, out_b, !last, tap);
             if (rc) return rc;
         }
@@ -1704,7 +1705,8 @@ int flagger_impl(const void* vis, int vis_dtype, const uint8_t* flags, uint8_t* 
                  size_t workspace_bytes, void* stream, Debug* dbg) {
     if (!vis || !flags || !out_flags || !p) return set_err(TRI_EINVAL, "NULL pointer argument");
     if (n_cp < 0) return set_err(TRI_EINVAL, "negative window count");
-    if (vis_dtype != TRI_VIS_C64 && vis_dtype != TRI_VIS_F32) return set_err(TRI_EUNSUPPORTED, "vis dtype must be complex64 or float32");
+    if (vis_dtype != TRI_VIS_C64 && vis_dtype != TRI_VIS_F32 && vis_dtype != TRI_VIS_F64)
+        return set_err(TRI_EUNSUPPORTED, "vis dtype must be complex64, float32 or float64 amplitudes");
     Run r;
     r.st = (hipStream_t)stream;
     r.p = p;
@@ -1714,6 +1716,7 @@ int flagger_impl(const void* vis, int vis_dtype, const uint8_t* flags, uint8_t* 
     if (r.pl.G > TRI_MAX_CHUNKS) return set_err(TRI_EUNSUPPORTED, "at most %d frequency chunks", TRI_MAX_CHUNKS);
     // the 16-byte kernels need 16-byte aligned user buffers (torch allocations are)
     if ((((uintptr_t)vis) | ((uintptr_t)flags) | ((uintptr_t)out_flags)) & 15) r.pl.vec = false;
+    if (vis_dtype == TRI_VIS_F64) r.pl.vec = false;       // float64 amplitudes: the scalar preparation / final kernels (rare input type)
     if (n_cp == 0) return TRI_OK;
     if (!workspace) return set_err(TRI_EWORKSPACE, "NULL workspace");
     if (((uintptr_t)workspace & 255) != 0) return set_err(TRI_EINVAL, "workspace must be 256-byte aligned");

@@ -390,19 +390,24 @@ def _flag_device(torch, lib, p, vis, flags, average_freq, _debug):
         # its amplitude is np.abs in float64 -- for complex128 numba's hypot(re, im) -- and enters the
         # float32 accumulator `value` through one round-to-nearest (flagging.py:856-859).  Without
         # channel averaging that rounded amplitude IS the averaged sample, so it can be formed up front.
-        if int(average_freq) != 1:
-            raise NotImplementedError("float64 / complex128 visibilities with average_freq > 1 "
-                                      "(the shipped strategies all use average_freq = 1)")
+        # With channel averaging the float64 amplitude itself enters the accumulator -- the sum is formed in float64 and
+        # rounded to float32 at every step (flagging.py:858-859) -- so it goes to the library as float64 (TRI_VIS_F64); a
+        # visibility with a NaN part arrives as NaN (the final isnan(in_data), flagging.py:777-781).
+        wide = int(average_freq) != 1
         if code == -128:
             re, im = v.real, v.imag
-            # torch.hypot is correctly rounded on this path to within 1 ulp of float64: far inside the
-            # float32 rounding that follows; (inf, nan) -> inf like C99 hypot
+            # torch.hypot is within 1 ulp of float64 of libm's hypot: far inside the float32 rounding that follows;
+            # (inf, nan) -> inf like C99 hypot
             amp = torch.hypot(re, im)
             amp = torch.where(torch.isinf(re) | torch.isinf(im), torch.full_like(amp, float("inf")), amp)
-            v = amp.to(torch.float32)
+            # a NaN part always flags the sample in the end (flagging.py:777-781), also next to an infinite one
+            amp = torch.where(torch.isnan(re) | torch.isnan(im), torch.full_like(amp, float("nan")), amp)
         else:
-            v = v.abs().to(torch.float32)
-        code = _lib.TRI_VIS_F32
+            amp = v.abs()
+        if wide:
+            v, code = amp.contiguous(), _lib.TRI_VIS_F64
+        else:
+            v, code = amp.to(torch.float32), _lib.TRI_VIS_F32
     n_cp = nbl * ncorr
     with torch.cuda.device(device):
         out = torch.empty((nbl, ncorr, ntime, nchan), dtype=torch.uint8, device=device)
