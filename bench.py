@@ -62,6 +62,18 @@ PARAM_SETS = {
                        time_extend=3, freq_extend=3, freq_chunks=10, average_freq=1,
                        flag_all_time_frac=0.6, flag_all_freq_frac=0.8, rho=1.3,
                        num_major_iterations=1),
+    # conf/default.yaml:74-89 "final_st_broad"
+    "broad": dict(outlier_nsigma=10, windows_time=[1, 2, 4, 8], windows_freq=[1, 2, 4, 8],
+                  background_reject=2.0, background_iterations=5, spike_width_time=6.5,
+                  spike_width_freq=10.0, time_extend=3, freq_extend=3, freq_chunks=10,
+                  average_freq=1, flag_all_time_frac=0.6, flag_all_freq_frac=0.8, rho=1.3,
+                  num_major_iterations=1),
+    # conf/default.yaml:90-105 "final_st_narrow" (spike_width_time arrives as the integer 2)
+    "narrow": dict(outlier_nsigma=10, windows_time=[1, 2, 4, 8], windows_freq=[1, 2, 4, 8],
+                   background_reject=2.0, background_iterations=5, spike_width_time=2,
+                   spike_width_freq=10.0, time_extend=3, freq_extend=3, freq_chunks=10,
+                   average_freq=1, flag_all_time_frac=0.6, flag_all_freq_frac=0.8, rho=1.3,
+                   num_major_iterations=1),
 }
 # conf/default.yaml:37-45 "residual_flag_initial"
 UVCONTSUB_KW = dict(major_cycles=7, or_original_from_cycle=1, taylor_degrees=20, sigma=15.0)
