@@ -302,6 +302,11 @@ k_boxt_spec(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFl
 // tile row stride (floats): conflict-free column writes and row reads -- the staging writes go to rows s_pos (0 .. PF-1),
 // columns LPI j + s_line0: 34 spreads 16 positions x 2 lines over the 32 banks, 33 does it for 32 positions x 1 line
 __host__ __device__ constexpr int boxf_ts(int pf) { return pf >= 32 ? 33 : 34; }
+#ifndef BOXF_DOUBLE_STAGE
+#define BOXF_DOUBLE_STAGE 1
+#endif
+// blocks per staging load of the fused stage: whole 128-byte lines (2 x 16 positions) for the small radii
+__host__ __device__ constexpr int boxf_nsub(int ks) { return (BOXF_DOUBLE_STAGE && ks <= 16 && boxr_pf_f(ks) == 16) ? 2 : 1; }
 #define BOXF_TS 34
 // cache policy of the fused stage's streaming accesses (amplitudes in, results out: touched once): 0 = default;
 // 2 = non-temporal, so that they do not push the half-read input lines (64 of 128 bytes per block) out of L2
@@ -316,10 +321,15 @@ k_boxf(const float* __restrict__ srcW, unsigned img_gap,
        uint8_t* __restrict__ nanflag) {
     extern __shared__ float cf_ring[];
     constexpr int PF = boxr_pf_f(KS);
-    constexpr int UNR = boxr_lcm(KS, PF);
+    // Staging granularity: NSUB blocks of PF positions per load.  With PF = 16 a staging instruction takes 64 of a
+    // line's 128 bytes and the other half is fetched again a block later -- 60 % of the time from HBM (traffic 1.30 x
+    // algorithmic, profiles/r03_fetch_calibration.txt); NSUB = 2 stages whole 128-byte lines every second block.
+    constexpr int NSUB = boxf_nsub(KS);
+    constexpr int PL = PF * NSUB;                              // positions per staging load
+    constexpr int UNR = boxr_lcm(boxr_lcm(KS, PF), PL);
     constexpr int BT = 64;
-    constexpr int LPI = 32 / PF;                               // lines covered by one staging load instruction (per image)
-    constexpr int TS = boxf_ts(PF);
+    constexpr int LPI = 32 / PL;                               // lines covered by one staging load instruction (per image)
+    constexpr int TS = boxf_ts(PL);
     const int lane = threadIdx.x;
     const int half = lane >> 5;                                // 0: weight image, 1: data image
     const int hl = lane & 31;
@@ -330,8 +340,8 @@ k_boxf(const float* __restrict__ srcW, unsigned img_gap,
     const int R2x = 2 * r;
     const int d = R2x - KS;
     float* ring = cf_ring + lane;                              // element (slot, p) at ((slot*4)+p)*BT
-    float* tiles = cf_ring + (size_t)4 * d * BT;               // [2 images][PF][TS]
-    float* tile = tiles + (size_t)half * PF * TS;
+    float* tiles = cf_ring + (size_t)4 * d * BT;               // [2 images][PL][TS]
+    float* tile = tiles + (size_t)half * PL * TS;
     if (HASL)
         for (int k = 0; k < 4 * d; k++) ring[(size_t)k * BT] = 0.0f;
 
@@ -346,26 +356,26 @@ k_boxf(const float* __restrict__ srcW, unsigned img_gap,
     // staging: element e = j * 32 + hl of this half's [32 lines][PF positions] patch: line = e / PF,
     // position = e % PF -> PF consecutive lanes read PF * 4 contiguous bytes of one row.
     // Lines beyond C and positions beyond n are masked.
-    const int s_pos = hl % PF;
-    const int s_line0 = hl / PF;                               // + LPI j
+    const int s_pos = hl % PL;
+    const int s_line0 = hl / PL;                               // + LPI j
     // (the data image of a window starts img_gap elements after its weight image: one descriptor
     //  spans both, the data-image half of the wave adds the gap to its lane offset)
     const unsigned ldb = (unsigned)ld * 4u;
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(srcW + win * sws_img), 0, (int)((img_gap + (unsigned)C * (unsigned)ld) * 4u), 0x00020000);
     const int s_off = (int)((unsigned)s_line0 * ldb) + s_pos * 4 + (half ? (int)(img_gap * 4u) : 0);
-    float pre[PF];
+    float pre[PL];
     auto issue = [&](int t0) {
         const int sbase = (int)((unsigned)c0 * ldb) + t0 * 4;
-        if (t0 + PF <= n && c0 + 32 <= C) {
+        if (t0 + PL <= n && c0 + 32 <= C) {
 #pragma unroll
-            for (int j = 0; j < PF; j++)
+            for (int j = 0; j < PL; j++)
                 pre[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srs, s_off, sbase + (int)((unsigned)(LPI * j) * ldb), 0));
         } else {
             // lines beyond C / positions beyond n are masked (and their addresses kept inside the window)
             const bool tok = t0 + s_pos < n;
 #pragma unroll
-            for (int j = 0; j < PF; j++) {
+            for (int j = 0; j < PL; j++) {
                 const bool ok = tok && (c0 + LPI * j + s_line0 < C);
                 const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srs, ok ? s_off + sbase + (int)((unsigned)(LPI * j) * ldb) : 0, 0, 0));
                 pre[j] = ok ? v : 0.0f;
@@ -384,7 +394,7 @@ k_boxf(const float* __restrict__ srcW, unsigned img_gap,
     // scalar row offsets and immediates.
     const int hrow = (PF / 2) * half;                            // first position of this half within a block
     const int hoff = (colok ? c : 0) * 4 + (int)((unsigned)hrow * rowb);
-    const float* eb = tiles + (size_t)hrow * TS + hl;            // weight tile; the data tile is PF * TS further
+    const float* eb = tiles + (size_t)hrow * TS + hl;            // weight tile; the data tile is PL * TS further
     float dpre[PF / 2];
     auto issue_data = [&](int m0, bool fast) {
         const int i0 = m0 - 3 - 4 * r;                           // position of u = 0 (scalar)
@@ -415,35 +425,38 @@ k_boxf(const float* __restrict__ srcW, unsigned img_gap,
         for (int b = 0; b < UNR / PF; b++) {
             const int m0 = mb + b * PF;
             if (m0 < total) {
-                wave_sync();                                     // previous tile (and hand-over) fully consumed
+                const int ro = (b % NSUB) * PF;                  // this block's rows of the tile (static after unrolling)
+                if (b % NSUB == 0) {
+                    wave_sync();                                 // previous tile (and hand-over) fully consumed
 #pragma unroll
-                for (int j = 0; j < PF; j++) tile[s_pos * TS + LPI * j + s_line0] = pre[j];
-                wave_sync();                                     // tile of positions [m0, m0 + PF) in LDS
-                issue(m0 + PF);                                  // next tile's loads stay in flight during the arithmetic
+                    for (int j = 0; j < PL; j++) tile[s_pos * TS + LPI * j + s_line0] = pre[j];
+                    wave_sync();                                 // tile of positions [m0, m0 + PL) in LDS
+                    issue(m0 + PL);                              // next tile's loads stay in flight during the arithmetic
+                }
                 const bool fast = m0 >= 4 * r + 3 && m0 + PF <= n;
                 issue_data(m0, fast);
                 // (the sample of step u + 1 is read before step u's LDS writes, so its latency hides
                 //  behind a whole step of arithmetic)
-                float xin = tile[hl];
+                float xin = tile[ro * TS + hl];
                 if (fast) {
 #pragma unroll
                     for (int u = 0; u < PF; u++) {
-                        const float xnext = (u + 1 < PF) ? tile[(u + 1) * TS + hl] : 0.0f;
+                        const float xnext = (u + 1 < PF) ? tile[(ro + u + 1) * TS + hl] : 0.0f;
                         float* cell = ring + (size_t)lslot * BT4;
                         if (HASL) lslot = (lslot + 1 == d) ? 0 : lslot + 1;
                         const float* ncell = ring + (size_t)lslot * BT4;
-                        tile[u * TS + hl] = boxline_step<KS, float, double, HASL, true>(L, (b * PF + u) % KS, m0 + u, xin, n, R2x, cell, ncell, BT);
+                        tile[(ro + u) * TS + hl] = boxline_step<KS, float, double, HASL, true>(L, (b * PF + u) % KS, m0 + u, xin, n, R2x, cell, ncell, BT);
                         xin = xnext;
                         if (BOXR_SCHED_EVERY > 0 && u % (BOXR_SCHED_EVERY > 0 ? BOXR_SCHED_EVERY : 1) == 0) __builtin_amdgcn_sched_barrier(0);
                     }
                 } else {
 #pragma unroll
                     for (int u = 0; u < PF; u++) {
-                        const float xnext = (u + 1 < PF) ? tile[(u + 1) * TS + hl] : 0.0f;
+                        const float xnext = (u + 1 < PF) ? tile[(ro + u + 1) * TS + hl] : 0.0f;
                         float* cell = ring + (size_t)lslot * BT4;
                         if (HASL) lslot = (lslot + 1 == d) ? 0 : lslot + 1;
                         const float* ncell = ring + (size_t)lslot * BT4;
-                        tile[u * TS + hl] = boxline_step<KS, float, double, HASL, false>(L, (b * PF + u) % KS, m0 + u, xin, n, R2x, cell, ncell, BT);
+                        tile[(ro + u) * TS + hl] = boxline_step<KS, float, double, HASL, false>(L, (b * PF + u) % KS, m0 + u, xin, n, R2x, cell, ncell, BT);
                         xin = xnext;
                         if (BOXR_SCHED_EVERY > 0 && u % (BOXR_SCHED_EVERY > 0 ? BOXR_SCHED_EVERY : 1) == 0) __builtin_amdgcn_sched_barrier(0);
                     }
@@ -460,8 +473,8 @@ k_boxf(const float* __restrict__ srcW, unsigned img_gap,
                             if ((fast || (i >= 0 && i < n)) && colok) {
                                 if (!IEEE) active |= __builtin_amdgcn_ballot_w64(true);
                                 // deferred flagging.py:419
-                                const float wv = IEEE ? box_divide_ieee(eb[k * TS], denom) : box_divide(eb[k * TS], denom, okmask);
-                                const float ov = IEEE ? box_divide_ieee(eb[(PF + k) * TS], denom) : box_divide(eb[(PF + k) * TS], denom, okmask);
+                                const float wv = IEEE ? box_divide_ieee(eb[(ro + k) * TS], denom) : box_divide(eb[(ro + k) * TS], denom, okmask);
+                                const float ov = IEEE ? box_divide_ieee(eb[(PL + ro + k) * TS], denom) : box_divide(eb[(PL + ro + k) * TS], denom, okmask);
                                 const float bg = (wv == 0.0f) ? NAN : ov / wv;
                                 // fast blocks: i0 + k >= 0, the half's rows ride in the lane offset
                                 const int vo = fast ? hoff : (c * 4 + (int)((unsigned)i * rowb));

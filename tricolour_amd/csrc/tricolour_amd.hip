@@ -951,7 +951,7 @@ int launch_boxf_ks(const Run& r, const float* srcW, const float* srcO, float* ds
                    int n, int C, int ld, int rad, size_t sws_img, size_t dws, size_t ws_data, int64_t W, uint8_t* nanflag) {
     const BoxDenom denom = box_reciprocal(box_denominator(rad));
     const int d = 2 * rad - KS;
-    const size_t lds = ((size_t)4 * d * 64 + (size_t)2 * boxr_pf_f(KS) * boxf_ts(boxr_pf_f(KS))) * sizeof(float);
+    const size_t lds = ((size_t)4 * d * 64 + (size_t)2 * boxr_pf_f(KS) * boxf_nsub(KS) * boxf_ts(boxr_pf_f(KS) * boxf_nsub(KS))) * sizeof(float);
     // one descriptor per window spans both images: the data image must follow the weight image closely
     if (srcO <= srcW || ((uint64_t)(srcO - srcW) + (uint64_t)C * ld) * 4u >= (1ull << 31))
         return set_err(TRI_EUNSUPPORTED, "fused frequency stage: the data image must follow the weight image within 2^31 bytes");
