@@ -907,6 +907,27 @@ k_reject4_t(const float* __restrict__ resid, uint8_t* __restrict__ flags, uint8_
     }
 }
 
+// The rejection where the residual lies as ROWS [T][ld] (the exact row filter's output) and the background flags as
+// TF4 words [T / 4][C]: one thread per word = four times of one channel (flagging.py:567-574).  No FT image involved.
+// grid (ceil(C / 256), T4, W)
+__global__ void __launch_bounds__(256)
+k_reject_tf(const float* __restrict__ resid, unsigned* __restrict__ flags_t4, const double* __restrict__ med,
+            const int* __restrict__ chunk_of, double scale, int T4, int C, int ld, int G, size_t ws_resid, size_t ws_words) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int q = blockIdx.y;
+    const size_t win = blockIdx.z;
+    const double thr = med[win * G + chunk_of[c]] * scale;
+    const float* rr = resid + win * ws_resid + (size_t)(4 * q) * ld + c;
+    unsigned* pw = flags_t4 + win * ws_words + (size_t)q * C + c;
+    unsigned f = *pw;
+    if ((double)rr[0] > thr) f = (f & 0xFFFFFF00u) | 0x00000001u;
+    if ((double)rr[(size_t)ld] > thr) f = (f & 0xFFFF00FFu) | 0x00000100u;
+    if ((double)rr[(size_t)2 * ld] > thr) f = (f & 0xFF00FFFFu) | 0x00010000u;
+    if ((double)rr[(size_t)3 * ld] > thr) f = (f & 0x00FFFFFFu) | 0x01000000u;
+    *pw = f;
+}
+
 __global__ void k_reject4(const float* __restrict__ resid, uint8_t* __restrict__ flags,
                           const double* __restrict__ med, const int* __restrict__ chunk_of,
                           double scale, int C4, int G, size_t n4per, size_t ws_resid, size_t ws_flags) {

@@ -306,12 +306,18 @@ __device__ __forceinline__ Sel3State select3(unsigned* hist, unsigned* sh, ENUM&
     return st;
 }
 
-template <bool VEC>
+// TFB (round 3): the segment is a 2-D BLOCK of a row-major image -- all tf_T4 * 4 rows (times) x the columns
+// [seg_start[g], + seg_len[g]) of rows of tf_ld elements -- with its flags packed four rows per 32-bit word
+// ("TF4": word (q, c) holds the flag bytes of rows 4q .. 4q + 3 at column c, rows of tf_ld words).  That is what the
+// rejection loop has when the exact row filter (K4x) leaves |data - background| as rows: the block median is taken
+// where the rows lie, no transpose to the FT slab.  The select itself is the same (any enumeration order selects exactly).
+template <bool VEC, bool TFB = false>
 __global__ void __launch_bounds__(256)
 k_median2(const float* __restrict__ data, const uint8_t* __restrict__ flags,
           double* __restrict__ med, size_t WSd, size_t WSf, size_t RS, size_t ES,
           const int64_t* __restrict__ seg_start, const int64_t* __restrict__ seg_len,
-          int R, int G, unsigned* __restrict__ gcand = nullptr, size_t cand_ws = 0, unsigned cand_cap = 0) {
+          int R, int G, unsigned* __restrict__ gcand = nullptr, size_t cand_ws = 0, unsigned cand_cap = 0,
+          int tf_T4 = 0, int tf_ld = 0) {
     __shared__ unsigned hist[SEL_BINS];
     __shared__ unsigned cand[SEL2_CAND];
     __shared__ unsigned sh[9];
@@ -319,16 +325,52 @@ k_median2(const float* __restrict__ data, const uint8_t* __restrict__ flags,
     const int seg = blockIdx.x;
     const int row = seg / G, g = seg % G;
     const size_t win = blockIdx.y;
-    const int64_t len = seg_len[g];
-    const size_t rel = (size_t)row * RS + (size_t)seg_start[g] * ES;
+    const int64_t len = TFB ? seg_len[g] * (4 * (int64_t)tf_T4) : seg_len[g];
+    const size_t rel = TFB ? (size_t)0 : (size_t)row * RS + (size_t)seg_start[g] * ES;
     data += win * WSd + rel;
     flags += win * WSf + rel;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int mis = VEC ? (int)(seg_start[g] & 3) : 0;           // VEC: rows are 16-byte aligned, segments need not be
+    const int mis = (VEC && !TFB) ? (int)(seg_start[g] & 3) : 0;  // VEC: rows are 16-byte aligned, segments need not be
+    const int tf_c0 = TFB ? (int)seg_start[g] : 0, tf_cl = TFB ? (int)seg_len[g] : 1;
+    const unsigned* tf_w = reinterpret_cast<const unsigned*>(flags);
+    // TFB: the sample at row t, column c of the block -> its key; false when flagged
+    auto tf_key_tc = [&](int t, int c, unsigned& k) -> bool {
+        const unsigned w = tf_w[(size_t)(t >> 2) * tf_ld + tf_c0 + c];
+        k = __float_as_uint(data[(size_t)t * tf_ld + tf_c0 + c]) & 0x7FFFFFFFu;
+        return ((w >> (8 * (t & 3))) & 0xFFu) == 0u;
+    };
+    // ... sample i of the block counted row by row (host: the block has fewer than 2^31 samples; 32-bit division)
+    auto tf_key = [&](int64_t i, unsigned& k) -> bool {
+        const unsigned iu = (unsigned)i, t = iu / (unsigned)tf_cl;
+        return tf_key_tc((int)t, (int)(iu - t * (unsigned)tf_cl), k);
+    };
 
     // every unflagged key of the segment, in this thread's share
     auto enumerate_all = [&](auto&& visit) {
-        if (VEC) {
+        if (TFB) {
+            // wave w takes the word rows q = w, w + 4, ...; lanes run along the block's columns, two groups of 64 in flight
+            // (four measured slower: 10.5 against 8.5 ms): one flag word + four samples (rows 4q .. 4q + 3) per column
+            for (int q = wave; q < tf_T4; q += 4) {
+                const unsigned* wr = tf_w + (size_t)q * tf_ld + tf_c0;
+                const float* dr = data + (size_t)(4 * q) * tf_ld + tf_c0;
+                for (int c = lane; c < tf_cl; c += 128) {
+                    const int c2 = c + 64;
+                    const bool two = c2 < tf_cl;
+                    const unsigned w0 = wr[c], w1 = two ? wr[c2] : 0x01010101u;
+                    float v0[4], v1[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        v0[k] = dr[(size_t)k * tf_ld + c];
+                        v1[k] = two ? dr[(size_t)k * tf_ld + c2] : 0.0f;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if (!((w0 >> (8 * k)) & 0xFFu)) visit(__float_as_uint(v0[k]) & 0x7FFFFFFFu);
+                        if (!((w1 >> (8 * k)) & 0xFFu)) visit(__float_as_uint(v1[k]) & 0x7FFFFFFFu);
+                    }
+                }
+            }
+        } else if (VEC) {
             // 16-byte groups of the (16-byte aligned) row that cover the segment; a segment may start and
             // end inside a group (mis = its offset in the first one): only the first and last group are masked
             const float4* d4 = reinterpret_cast<const float4*>(data - mis);
@@ -401,11 +443,16 @@ k_median2(const float* __restrict__ data, const uint8_t* __restrict__ flags,
         for (int j = 0; j < 8; j++) {
             const int64_t i = (int64_t)(j * 256 + tid) * stride;
             if (i < len) {
-                const size_t a = (size_t)i * ES;
-                if (!flags[a]) {
-                    const unsigned k = __float_as_uint(data[a]) & 0x7FFFFFFFu;
-                    kmin = min(kmin, k);
-                    kmax = max(kmax, k);
+                if (TFB) {
+                    unsigned k;
+                    if (tf_key(i, k)) { kmin = min(kmin, k); kmax = max(kmax, k); }
+                } else {
+                    const size_t a = (size_t)i * ES;
+                    if (!flags[a]) {
+                        const unsigned k = __float_as_uint(data[a]) & 0x7FFFFFFFu;
+                        kmin = min(kmin, k);
+                        kmax = max(kmax, k);
+                    }
                 }
             }
         }
@@ -484,7 +531,7 @@ k_median2(const float* __restrict__ data, const uint8_t* __restrict__ flags,
     // MED2_WIN bins of the prediction to the candidate buffer in global memory (~2.5 % of the keys); when the
     // true bin -- known once the histogram is complete -- lies inside that window, the exact select runs on
     // the candidates and the segment has been read ONCE.  A miss costs the second pass it always used to.
-    bool predict = gcand != nullptr && hi >= lo && len >= 65536 && ES == 1;
+    bool predict = gcand != nullptr && hi >= lo && len >= 65536 && (ES == 1 || TFB);
     unsigned wlo = 1, whi = 0;
     if (predict) {
 #pragma unroll
@@ -494,7 +541,13 @@ k_median2(const float* __restrict__ data, const uint8_t* __restrict__ flags,
 #pragma unroll 8
         for (int rr = 0; rr < 64; rr++) {
             const int64_t i = rr * rstep + tid;
-            if (!flags[i]) atomicAdd(&hist[bin_of(__float_as_uint(data[i]) & 0x7FFFFFFFu)], 1u);
+            if (TFB) {
+                // (64 runs of up to 256 consecutive columns, one run in every 64th part of the rows: no division per sample)
+                const int T = 4 * tf_T4;
+                const int t = (int)(((int64_t)rr * T) >> 6);
+                unsigned k;
+                if (tid < tf_cl && tf_key_tc(t, tid, k)) atomicAdd(&hist[bin_of(k)], 1u);
+            } else if (!flags[i]) atomicAdd(&hist[bin_of(__float_as_uint(data[i]) & 0x7FFFFFFFu)], 1u);
         }
         __syncthreads();
         const unsigned ns = locate(1);

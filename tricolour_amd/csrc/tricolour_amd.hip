@@ -1272,6 +1272,7 @@ int background2d(const Run& r, bool flagsFT_current) {
         if (rc) return rc;
     }
     double rej = TRI_MAD_NORMAL * r.p->background_reject;
+    bool bgf_ft_stale = false;           // the FT flag bytes lag behind the TF4 words (rows-only rejection iterations)
     for (int ext = pl.nit; ext >= 0; ext--) {
         bool final_pass = ext == 0;
         double e = (double)(final_pass ? 1 : ext);
@@ -1289,6 +1290,18 @@ int background2d(const Run& r, bool flagsFT_current) {
         const int ksf = ((uint64_t)N * 4u < (1ull << 31) && ((uint64_t)(ws.Ao - ws.Aw) + N) * 4u < (1ull << 31)) ? boxr_pick_ks_f(r1) : 0;
         // exact row filter (K4x) where the stage pipelines end: rows of the time stage's TF images in, rows out
         const int xl = (r1 > 0 && (!ksf || r1 >= BOXX_MIN_R) && (!r.ampl_cached || r.data_mask)) ? boxx_pick_l(r1, Fa) : 0;
+        // ... whose rejection iterations then stay in the row layout altogether (TRI_FILTER_NO_TF_REJECT=1: transposes + FT kernels)
+        static const bool no_tfr = [] { const char* e = getenv("TRI_FILTER_NO_TF_REJECT"); return e && e[0] == '1'; }();
+        const bool tf_native = xl > 0 && !final_pass && packed && !no_tfr && G <= 65535 && (uint64_t)T * Fa * 4u < (1ull << 31);
+        // (who reads the FT bytes: a time stage that cannot take the TF4 words, and the median / rejection of an FT-native
+        //  iteration; the final pass has neither median nor rejection)
+        const bool time_from_tf4 = r0 > 0 && packed && colfilter_lds_block(r0, Fa) > 0;
+        if (bgf_ft_stale && (!time_from_tf4 || (!final_pass && !tf_native))) {
+            // an iteration that reads the FT flag bytes follows rows-only ones: they are the 32-bit transpose of the TF4 words
+            rc = launch_transpose<float>(r, reinterpret_cast<const float*>(ws.bgfTF), reinterpret_cast<float*>(ws.bgfFT), T / 4, Fa, N / 4, N / 4, W);
+            if (rc) return rc;
+            bgf_ft_stale = false;
+        }
         const bool tin4 = !xl && !ksf && !colfilter_t_usable(r1) && colfilter_t4_usable(r1);
         const bool tin = xl > 0 || ksf > 0 || colfilter_t_usable(r1) || tin4;
         float* den_t_ptr = tin ? nullptr : &den_t;
@@ -1352,6 +1365,25 @@ int background2d(const Run& r, bool flagsFT_current) {
                 rc = launch_transpose<float>(r, ws.Aw, ws.Bw, T, Fa, wsA, wsB, W);
             } else {
                 rc = launch_boxx<1>(r, xl, ws.Aw, ws.Ao, ws.dataTF, mk, ws.Ao, nullptr, Fa, T, Fa, r1, wsA, N, r.data_mask_ws, wsA, 0, W, nullptr);
+                if (rc) return rc;
+                if (tf_native) {
+                    // the rejection where the rows lie: block medians over (all times) x (chunk channels) of the row image
+                    // with the TF4 flag words, rejection straight into those words -- no FT image of the residual or of
+                    // the flags in this iteration (the FT flags are rebuilt when an FT-native iteration follows)
+                    static const bool no_predict = [] { const char* e = getenv("TRI_MEDIAN_NO_PREDICT"); return e && e[0] == '1'; }();
+                    unsigned* gc = reinterpret_cast<unsigned*>(ws.Aw);          // the weight rows are dead: candidate scratch
+                    unsigned cap = (unsigned)(std::min<size_t>((wsA / 2) / (size_t)G, 0x7fffffffu) & ~(size_t)3);
+                    if (no_predict || (int64_t)cap < pl.maxchunk * pl.T || wsA % 4 != 0) { gc = nullptr; cap = 0; }
+                    hipLaunchKernelGGL((k_median2<false, true>), dim3((unsigned)G, (unsigned)W), dim3(256), 0, r.st, (const float*)ws.Ao,
+                                       (const uint8_t*)ws.bgfTF, ws.med, wsA, N, (size_t)0, (size_t)1, ws.segC_start, ws.segC_len, 1, G,
+                                       gc, gc ? wsA : (size_t)0, cap, T / 4, Fa);
+                    hipLaunchKernelGGL(k_reject_tf, dim3((unsigned)cdiv(Fa, 256), (unsigned)(T / 4), (unsigned)W), dim3(256), 0, r.st,
+                                       (const float*)ws.Ao, reinterpret_cast<unsigned*>(ws.bgfTF), ws.med, ws.d_chunk_of, rej, T / 4, Fa, Fa, G,
+                                       wsA, N / 4);
+                    LAUNCHCHK();
+                    bgf_ft_stale = true;
+                    continue;
+                }
             }
             if (rc) return rc;
             rc = launch_transpose<float>(r, ws.Ao, ws.Bo, T, Fa, wsA, wsB, W);
