@@ -349,24 +349,28 @@ k_median2(const float* __restrict__ data, const uint8_t* __restrict__ flags,
     auto enumerate_all = [&](auto&& visit) {
         if (TFB) {
             // wave w takes the word rows q = w, w + 4, ...; lanes run along the block's columns, two groups of 64 in flight
-            // (four measured slower: 10.5 against 8.5 ms): one flag word + four samples (rows 4q .. 4q + 3) per column
+            // (four measured slower): one flag word + four samples (rows 4q .. 4q + 3) per column.  Buffer addressing: a lane
+            // offset per column group and scalar row offsets -- no 64-bit address arithmetic per load (host: image < 2^31 bytes)
+            const unsigned rowb = (unsigned)tf_ld * 4u;
+            const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)data, 0, (int)((unsigned)(4 * tf_T4) * rowb), 0x00020000);
+            const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)tf_w, 0, (int)((unsigned)tf_T4 * rowb), 0x00020000);
             for (int q = wave; q < tf_T4; q += 4) {
-                const unsigned* wr = tf_w + (size_t)q * tf_ld + tf_c0;
-                const float* dr = data + (size_t)(4 * q) * tf_ld + tf_c0;
+                const int sw = (int)((unsigned)q * rowb), sd = (int)((unsigned)(4 * q) * rowb);
                 for (int c = lane; c < tf_cl; c += 128) {
-                    const int c2 = c + 64;
-                    const bool two = c2 < tf_cl;
-                    const unsigned w0 = wr[c], w1 = two ? wr[c2] : 0x01010101u;
-                    float v0[4], v1[4];
+                    const bool two = c + 64 < tf_cl;
+                    const int vo0 = (tf_c0 + c) * 4, vo1 = two ? vo0 + 256 : 0x7ffffff0;     // (out of range: loads return 0, never visited)
+                    const unsigned w0 = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(wrs, vo0, sw, 0);
+                    const unsigned w1 = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(wrs, vo1, sw, 0);
+                    unsigned v0[4], v1[4];
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        v0[k] = dr[(size_t)k * tf_ld + c];
-                        v1[k] = two ? dr[(size_t)k * tf_ld + c2] : 0.0f;
+                        v0[k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(drs, vo0, sd + (int)((unsigned)k * rowb), 0);
+                        v1[k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(drs, vo1, sd + (int)((unsigned)k * rowb), 0);
                     }
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        if (!((w0 >> (8 * k)) & 0xFFu)) visit(__float_as_uint(v0[k]) & 0x7FFFFFFFu);
-                        if (!((w1 >> (8 * k)) & 0xFFu)) visit(__float_as_uint(v1[k]) & 0x7FFFFFFFu);
+                        if (!((w0 >> (8 * k)) & 0xFFu)) visit(v0[k] & 0x7FFFFFFFu);
+                        if (two && !((w1 >> (8 * k)) & 0xFFu)) visit(v1[k] & 0x7FFFFFFFu);
                     }
                 }
             }
