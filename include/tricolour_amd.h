@@ -295,6 +295,9 @@ int tri_bench_sumthreshold(const float *data, const double *mad, uint8_t *out,
  * For stage 1 also: 3 = the eight-wave stage pipeline (K4qf), 4 = the exact
  * row filter (K4x: one line pair resident in LDS, lanes = positions, any
  * radius; the time covers the kernel and the transpose of its rows to out_o).
+ * Stages 0 and 1: 3 = the stage pipeline (K4q / K4qf) with the block length the
+ * flagger would take (8 positions while the delay line fits 128 registers,
+ * else 16), 5 = the same with blocks of 16 positions throughout.
  */
 int tri_bench_boxfilter(const float *data, const uint8_t *flags4, float *out_w,
                         float *out_o, int64_t n_win, int64_t n_line, int64_t n_col,

@@ -165,18 +165,20 @@ def _time_stage(data, flags, radius, variant):
 
 @pytest.mark.parametrize("shape,radius", [((2, 64, 70), 8), ((1, 256, 64), 10), ((2, 1024, 130), 21), ((1, 512, 64), 32),
                                           ((2, 1024, 70), 43), ((1, 1024, 200), 54), ((1, 128, 64), 27), ((2, 64, 6), 15),
-                                          ((1, 16, 64), 54), ((1, 2048, 64), 12)])
+                                          ((1, 16, 64), 54), ((1, 2048, 64), 12), ((1, 256, 64), 28), ((1, 260, 70), 36),
+                                          ((2, 256, 64), 40), ((1, 128, 130), 16), ((1, 512, 64), 35)])
 def test_time_stage_routes(gpu, shape, radius):
     """Time-axis stage of the 2-D background filter: LDS delay lines (variant 1), register delay lines K4r (2), the
-    four-wave stage pipeline K4q (3) and the flagger's own route (0) agree bit for bit -- every (register part, FIFO
-    delay) split of the delay line, lines shorter than the filter, ragged column counts, NaN data under flags."""
+    four-wave stage pipeline K4q with blocks of 8 where they apply (3) and of 16 throughout (5) and the flagger's own
+    route (0) agree bit for bit -- every (register part, FIFO delay) split of the delay line, lines shorter than the
+    filter, ragged column counts, NaN data under flags."""
     rs = np.random.RandomState(radius * 100 + shape[1])
     data = (rs.standard_normal(shape) * 3 + 10).astype(np.float32)
     flags = rs.uniform(size=shape) < 0.1
     flags[:, shape[1] // 3: shape[1] // 3 + 3 * radius, 0] = True       # a gap wider than the filter
     data[flags & (rs.uniform(size=shape) < 0.3)] = np.nan
     ref = _time_stage(data, flags, radius, 1)
-    for variant in (2, 3, 0):
+    for variant in (2, 3, 5, 0):
         got = _time_stage(data, flags, radius, variant)
         for name, a, b in (("weights", ref[0], got[0]), ("data", ref[1], got[1])):
             ok = _same_f32(a, b)
@@ -204,11 +206,13 @@ def _freq_stage(wimg, oimg, data, radius, variant):
 
 @pytest.mark.parametrize("shape,radius", [((2, 64, 128), 8), ((1, 72, 256), 10), ((2, 132, 1024), 21), ((1, 64, 512), 32),
                                           ((2, 36, 1024), 43), ((1, 200, 1024), 54), ((1, 64, 128), 27), ((1, 8, 64), 17),
-                                          ((1, 64, 16), 54)])
+                                          ((1, 64, 16), 54), ((1, 72, 256), 34), ((1, 64, 512), 38), ((2, 64, 256), 40),
+                                          ((1, 132, 512), 30), ((1, 64, 512), 46)])
 def test_frequency_stage_routes(gpu, shape, radius):
     """Frequency-axis stage fused with the masked division: LDS delay lines (variant 1), register delay lines
-    K4r (2), the eight-wave stage pipeline K4qf (3) and the flagger's own route (0) agree bit for bit, including
-    zero-weight bands (NaN background), lines shorter than the filter and ragged line counts."""
+    K4r (2), the eight-wave stage pipeline K4qf with blocks of 8 where they apply (3) and of 16 throughout (5) and the
+    flagger's own route (0) agree bit for bit, including zero-weight bands (NaN background), lines shorter than the
+    filter and ragged line counts."""
     w, t, f = shape
     rs = np.random.RandomState(radius * 100 + f)
     wimg = (rs.uniform(size=shape) * 0.9 + 0.05).astype(np.float32)
@@ -217,7 +221,7 @@ def test_frequency_stage_routes(gpu, shape, radius):
     oimg = (wimg * (rs.standard_normal(shape) * 3 + 10)).astype(np.float32)
     data = (rs.standard_normal((w, f, t)) * 3 + 10).astype(np.float32)
     ref = _freq_stage(wimg, oimg, data, radius, 1)
-    for variant in (2, 3, 0):
+    for variant in (2, 3, 5, 0):
         got = _freq_stage(wimg, oimg, data, radius, variant)
         ok = _same_f32(ref, got)
         assert ok.all(), "variant %d: %d of %d words differ (first at %s)" % (variant, (~ok).sum(), ok.size, np.argwhere(~ok)[0])

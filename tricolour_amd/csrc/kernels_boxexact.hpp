@@ -295,6 +295,7 @@ k_boxx(const float* srcW, unsigned img_gap, const float* __restrict__ data, cons
 #pragma unroll
             for (int k = 0; k < 4; k++) { wq[k] = box_divide(wa[k], denom, okm); oq[k] = box_divide(oa[k], denom, okm); }
             if (okm != ~0ull) {
+                TRI_KEEP_BRANCH();
 #pragma unroll
                 for (int k = 0; k < 4; k++) { wq[k] = box_divide_ieee(wa[k], denom); oq[k] = box_divide_ieee(oa[k], denom); }
             }

@@ -227,7 +227,8 @@ k_boxp_spec(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFl
 // stages / stores positions 4w .. 4w + 3 of column l: one flag word covers them.
 // grid (ceil(C / 64), W), block 256; host: n % 4 == 0, window below 2^31 bytes, 16 <= 2r, 2r - KS < 16.
 // ---------------------------------------------------------------------------
-#define BOXQ_LDS_BYTES ((4 * 4 * 16 * 64 + 2 * 16 * 64) * 4)   // 72 KB: two workgroups per compute unit
+__host__ __device__ constexpr size_t boxq_lds_bytes(int B) { return (size_t)(4 * 4 * B * 64 + 2 * B * 64) * 4; }
+#define BOXQ_LDS_BYTES boxq_lds_bytes(16)   // 72 KB: two workgroups per compute unit (B = 8: 36 KB, four)
 __host__ __device__ constexpr int boxq_prefetch(int ks) { return ks == 48 || ks == 96 ? 6 : (ks == 80 ? 5 : 4); }
 #ifndef BOXQ_ABLATE
 #define BOXQ_ABLATE 0                    // timing-only builds: 1 = no finishing, 2 = no stage arithmetic, 4 = no staging / loads
@@ -238,17 +239,23 @@ __host__ __device__ constexpr int boxq_lcm(int a, int b) {
     return a / x * b;
 }
 
-template <int IMG, int KS, int P>
+// blocks of 8 positions: prefetch depth for KS / 8 register blocks (P divides or is divided by it: short unroll; 128 registers)
+__host__ __device__ constexpr int boxq_prefetch8(int nblk) {
+    return nblk == 6 ? 3 : (nblk == 8 ? 4 : (nblk == 9 ? 3 : (nblk == 10 ? 2 : (nblk == 12 ? 4 : nblk))));
+}
+
+template <int IMG, int KS, int P, int B = 16>
 __device__ __forceinline__ void boxq_body(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags,
                                           float* __restrict__ dst, const int n, const int C, const int r, const BoxDenom denom,
                                           const size_t sws, const size_t dws, const size_t win) {
     using V = typename std::conditional<IMG == 0, int, float>::type;
     using A = typename std::conditional<IMG == 0, int, double>::type;
-    constexpr int B = 16;
+    constexpr int PPT = B / 4;                                 // positions per thread when staging / storing (4 or 2)
     constexpr int NBLK = KS / B;
     constexpr int U = boxq_lcm(NBLK, P);
     constexpr unsigned OOB = 0x7ffffff0u;
     static_assert(KS % B == 0 && KS >= B, "register part: whole blocks");
+    static_assert(B == 8 || B == 16, "block length");
     extern __shared__ float cf_ring[];                         // dynamic LDS: BOXQ_LDS_BYTES
     typedef V FifoT[4 * B][64];                                // one stage's input stream: 3 blocks + mirror of the first
     typedef float OutT[B][64];
@@ -269,14 +276,14 @@ __device__ __forceinline__ void boxq_body(const float* __restrict__ srcData, con
     for (int k = tid; k < 4 * 4 * B * 64; k += 256) reinterpret_cast<V*>(cf_ring)[k] = 0;
 
     unsigned pref[P];                                          // TF4 word: flags of positions 4w .. 4w + 3
-    float prex[IMG == 1 ? P : 1][4];
+    float prex[IMG == 1 ? P : 1][PPT];
     auto issue = [&](int blk, int q) {
-        const int t = blk * B + 4 * wave;                      // multiple of 4; n % 4 == 0: all four positions in or out
+        const int t = blk * B + PPT * wave;                    // multiple of 4 (2); n % 4 == 0: all its positions in or out
         const bool ok = colok && t < n;
         pref[q] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(frs, (int)(ok ? (unsigned)(t >> 2) * rowb + coff : OOB), 0, 0);
         if (IMG == 1) {
 #pragma unroll
-            for (int k = 0; k < 4; k++)
+            for (int k = 0; k < PPT; k++)
                 prex[q][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, (int)(ok ? (unsigned)(t + k) * rowb + coff : OOB), 0, 0));
         }
     };
@@ -304,21 +311,22 @@ __device__ __forceinline__ void boxq_body(const float* __restrict__ srcData, con
             const int sb = (qq % NBLK) * B;                    // register delay-line slots of this iteration (static)
 #if !(BOXQ_ABLATE & 4)
             {                                                  // stage block j into the stage-1 FIFO (LDS only)
-                const int t = j * B + 4 * wave;
+                const int t = j * B + PPT * wave;
                 const bool tin = colok && t < n;               // beyond the line end: flagged
-                V sv[4];
+                const unsigned fw = PPT == 4 ? pref[q] : pref[q] >> (16 * (wave & 1));   // (B = 8: the word's upper half for odd waves)
+                V sv[PPT];
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const bool fl = !tin || ((pref[q] >> (8 * k)) & 0xFFu) != 0;
+                for (int k = 0; k < PPT; k++) {
+                    const bool fl = !tin || ((fw >> (8 * k)) & 0xFFu) != 0;
                     if (IMG == 0) sv[k] = fl ? (V)0 : (V)1;
                     else sv[k] = fl ? (V)0 : (V)prex[IMG == 1 ? q : 0][k];
                 }
-                V* p = &fifo[0][lslot * B + 4 * wave][lane];
+                V* p = &fifo[0][lslot * B + PPT * wave][lane];
 #pragma unroll
-                for (int k = 0; k < 4; k++) p[k * 64] = sv[k];
+                for (int k = 0; k < PPT; k++) p[k * 64] = sv[k];
                 if (lslot == 0) {
 #pragma unroll
-                    for (int k = 0; k < 4; k++) p[(3 * B + k) * 64] = sv[k];
+                    for (int k = 0; k < PPT; k++) p[(3 * B + k) * 64] = sv[k];
                 }
                 lslot = lslot == 2 ? 0 : lslot + 1;
             }
@@ -370,20 +378,21 @@ __device__ __forceinline__ void boxq_body(const float* __restrict__ srcData, con
 #if !(BOXQ_ABLATE & 1)
             {                                                  // store block j - 5 (always issued)
                 const int bs = j - 5;
-                const int i0 = bs * B + 4 * wave - 4 * r;
-                const float* ob = &outb[bs & 1][4 * wave][lane];
+                const int i0 = bs * B + PPT * wave - 4 * r;
+                const float* ob = &outb[bs & 1][PPT * wave][lane];
                 // division by the launch constant through its reciprocal (kernels_boxline.hpp: exact wherever the
                 // class test passes, checked for all 2^32 inputs per radius; anything else is redone by IEEE division)
-                float a[4], y[4];
+                float a[PPT], y[PPT];
                 unsigned long long okm = ~0ull;
 #pragma unroll
-                for (int k = 0; k < 4; k++) { a[k] = ob[k * 64]; y[k] = box_divide(a[k], denom, okm); }
+                for (int k = 0; k < PPT; k++) { a[k] = ob[k * 64]; y[k] = box_divide(a[k], denom, okm); }
                 if (okm != ~0ull) {
+                    TRI_KEEP_BRANCH();
 #pragma unroll
-                    for (int k = 0; k < 4; k++) y[k] = box_divide_ieee(a[k], denom);
+                    for (int k = 0; k < PPT; k++) y[k] = box_divide_ieee(a[k], denom);
                 }
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
+                for (int k = 0; k < PPT; k++) {
                     const int i = i0 + k;
                     const bool ok = bs >= 0 && bs < NB && i >= 0 && i < n && colok;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[k]), ors, (int)(ok ? (unsigned)i * rowb + coff : OOB), 0, 0);
@@ -395,11 +404,13 @@ __device__ __forceinline__ void boxq_body(const float* __restrict__ srcData, con
     }
 }
 
-template <int KS, int IMG>
-__global__ void __launch_bounds__(256, 2)
+// (HIP: the second __launch_bounds__ argument counts WAVES PER SIMD.)  B = 8: 36 KB of LDS and at most 128 registers:
+// four workgroups = four waves per SIMD, for delay lines of up to 80 registers; host: 2r - KS < 8.
+template <int KS, int IMG, int B = 16>
+__global__ void __launch_bounds__(256, B == 8 ? 4 : 2)
 k_boxq(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags, float* __restrict__ dstImg,
        int n, int C, int r, BoxDenom denom, size_t sws, size_t dws) {
-    boxq_body<IMG, KS, boxq_prefetch(KS)>(srcData, srcFlags, dstImg, n, C, r, denom, sws, dws, blockIdx.y);
+    boxq_body<IMG, KS, B == 8 ? boxq_prefetch8(KS / 8) : boxq_prefetch(KS), B>(srcData, srcFlags, dstImg, n, C, r, denom, sws, dws, blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------
@@ -427,17 +438,29 @@ k_boxq(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags, 
 #endif
 __host__ __device__ constexpr size_t boxqf_lds_bytes(int B) { return (size_t)(2 * 4 * 4 * B * BOXQF_LW + 2 * 2 * B * BOXQF_LW) * 4; }
 #define BOXQF_LDS_BYTES boxqf_lds_bytes(16)
-// B = 8: half the FIFO memory and, for delay lines of up to 48 registers, half the register budget: TWO workgroups
+// B = 8: half the FIFO memory and, for delay lines of up to 80 registers, half the register budget: TWO workgroups
 // (four waves per SIMD) share a compute unit -- twice the barriers per position against twice the latency hiding.
+// Occupancy, not instruction count, is what this kernel's time follows: at two waves per SIMD (B = 16) dropping 22
+// vector instructions per sample changed nothing (22.1 ms), at four waves (B = 8) the same cut took 19.0 -> 17.3 ms.
+#ifndef BOXQF_P10
+#define BOXQF_P10 2                      // KS = 80 at B = 8: two blocks ahead is what 128 registers leave (5: 13 dwords of scratch, 23 ms instead of 17.8)
+#endif
+__host__ __device__ constexpr int boxqf_prefetch8(int nblk) {
+    return nblk == 6 ? 3 : (nblk == 8 ? 4 : (nblk == 9 ? 3 : (nblk == 10 ? BOXQF_P10 : (nblk == 12 ? 4 : nblk))));
+}
+#ifndef BOXQF_MINW8
+#define BOXQF_MINW8 4                    // HIP: the second __launch_bounds__ argument counts WAVES PER SIMD -- two 8-wave workgroups per CU need 4
+                                         // (with 2 the KS = 64 kernel took 130 registers: ONE workgroup per CU, 25 ms; bounded to 128 it runs in 17.7)
+#endif
 template <int KS, int MODE, int B = 16>
-__global__ void __launch_bounds__(512, B == 8 ? 2 : 1)
+__global__ void __launch_bounds__(512, B == 8 ? BOXQF_MINW8 : 1)
 k_boxqf(const float* __restrict__ srcW, unsigned img_gap, float* __restrict__ dstW, float* __restrict__ dstO,
         const float* __restrict__ data, int n, int C, int ld, int r, BoxDenom denom, size_t sws_img, size_t dws,
         size_t ws_data, uint8_t* __restrict__ nanflag) {
     constexpr int PP = B / 4;                                  // positions per thread when staging (4 or 2)
     constexpr int FN = B / 8;                                  // (position, line) pairs per thread when finishing (2 or 1)
     constexpr int NBLK = KS / B;
-    constexpr int P = B == 8 ? (NBLK == 6 ? 3 : (NBLK == 8 ? 4 : NBLK)) : boxq_prefetch(KS);   // (B = 8: KS = 32, 40, 48, 56, 64 -> 4, 5, 3, 7, 4 blocks ahead: 128 registers)
+    constexpr int P = B == 8 ? boxqf_prefetch8(NBLK) : boxq_prefetch(KS);   // (B = 8: KS = 32, 40, 48, 56, 64, 72, 80, 96 -> 4, 5, 3, 7, 4, 3, BOXQF_P10, 4 blocks ahead: 128 registers)
     static_assert(KS % B == 0, "register part: whole blocks");
     static_assert(B == 8 || B == 16, "block length");
     constexpr int U = boxq_lcm(NBLK, P);
@@ -581,6 +604,7 @@ k_boxqf(const float* __restrict__ srcW, unsigned img_gap, float* __restrict__ ds
                     oq[h] = box_divide(a1[h], denom, okm);
                 }
                 if (okm != ~0ull) {
+                    TRI_KEEP_BRANCH();
 #pragma unroll
                     for (int h = 0; h < FN; h++) { wq[h] = box_divide_ieee(a0[h], denom); oq[h] = box_divide_ieee(a1[h], denom); }
                 }

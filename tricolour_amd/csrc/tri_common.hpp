@@ -104,3 +104,7 @@ __device__ __forceinline__ bool load_isnan(const void* vis, size_t i) {
     }
 }
 
+// First statement of a rarely taken branch that must STAY a branch: the compiler otherwise if-converts short arms
+// (it did so for the IEEE-division fallback of box_divide(): both divisions were computed for every output and
+// selected afterwards, 22 extra vector instructions per sample).  A volatile asm cannot be executed speculatively.
+#define TRI_KEEP_BRANCH() asm volatile("; cold path")

@@ -605,7 +605,7 @@ int launch_boxp_spec_b(const Run& r, const float* srcData, const uint8_t* srcFla
 // K4q (kernels_boxpipe.hpp): register part of the delay lines for radius rad, 0 when it does not apply.
 // TRI_FILTER_NO_PIPE_T=1 keeps the K4r / LDS kernels.
 #ifndef BOXQ_MIN_2R
-#define BOXQ_MIN_2R 66
+#define BOXQ_MIN_2R 56
 #endif
 thread_local int g_boxq_override = -1;   // tests / benches: 0 = off, 1 = on wherever it applies
 static int boxq_pick_ks(int rad) {
@@ -615,25 +615,48 @@ static int boxq_pick_ks(int rad) {
     return (ks >= 16 && ks <= 96) ? ks : 0;
 }
 
-template <int KS>
+template <int KS, int B = 16>
 int launch_boxq_ks(const Run& r, const float* srcData, const uint8_t* srcFlags, float* dstW, float* dstO,
                    int n, int C, int rad, float denom, size_t sws, size_t dws, int64_t W) {
     const hipError_t attr = [] {
-        hipError_t e = lds_optin(reinterpret_cast<const void*>(&k_boxq<KS, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = lds_optin(reinterpret_cast<const void*>(&k_boxq<KS, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = lds_optin(reinterpret_cast<const void*>(&k_boxq<KS, 0, B>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = lds_optin(reinterpret_cast<const void*>(&k_boxq<KS, 1, B>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return e;
     }();
     HIPCHK(attr);
     dim3 grid((unsigned)cdiv(C, 64), (unsigned)W);
     const BoxDenom dn = box_reciprocal(denom);
-    hipLaunchKernelGGL((k_boxq<KS, 0>), grid, dim3(256), BOXQ_LDS_BYTES, r.st, srcData, srcFlags, dstW, n, C, rad, dn, sws, dws);
-    hipLaunchKernelGGL((k_boxq<KS, 1>), grid, dim3(256), BOXQ_LDS_BYTES, r.st, srcData, srcFlags, dstO, n, C, rad, dn, sws, dws);
+    hipLaunchKernelGGL((k_boxq<KS, 0, B>), grid, dim3(256), boxq_lds_bytes(B), r.st, srcData, srcFlags, dstW, n, C, rad, dn, sws, dws);
+    hipLaunchKernelGGL((k_boxq<KS, 1, B>), grid, dim3(256), boxq_lds_bytes(B), r.st, srcData, srcFlags, dstO, n, C, rad, dn, sws, dws);
     LAUNCHCHK();
     return TRI_OK;
 }
 
+// blocks of 8 positions (four workgroups = four waves per SIMD) while the delay line fits 128 registers: KS = 8 * floor(2r / 8)
+#ifndef BOXQ_B8_MIN_2R
+#define BOXQ_B8_MIN_2R 32
+#endif
+#ifndef BOXQ_B8_MAX2R
+#define BOXQ_B8_MAX2R 88
+#endif
+thread_local int g_boxq_b8_override = -1;   // tests: 0 = blocks of 16 only (time- and frequency-axis stage pipelines)
+static int boxq_pick_ks8(int rad) {
+    static const int b8 = [] { const char* e = getenv("TRI_FILTER_PIPE_T_B8"); return e ? atoi(e) : 1; }();
+    if (!b8 || g_boxq_b8_override == 0 || 2 * rad < BOXQ_B8_MIN_2R || 2 * rad >= BOXQ_B8_MAX2R) return 0;
+    return 2 * rad / 8 * 8;
+}
+
 int launch_boxq(const Run& r, int ks, const float* srcData, const uint8_t* srcFlags, float* dstW, float* dstO,
                 int n, int C, int rad, float denom, size_t sws, size_t dws, int64_t W) {
+    switch (boxq_pick_ks8(rad)) {
+        case 32: return launch_boxq_ks<32, 8>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
+        case 40: return launch_boxq_ks<40, 8>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
+        case 48: return launch_boxq_ks<48, 8>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
+        case 56: return launch_boxq_ks<56, 8>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
+        case 64: return launch_boxq_ks<64, 8>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
+        // (72: the data image's kernel would spill 7 registers at 128 -- blocks of 16 with KS = 64 take 2r = 72 .. 78)
+        case 80: return launch_boxq_ks<80, 8>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
+    }
     switch (ks) {
         case 16: return launch_boxq_ks<16>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
         case 32: return launch_boxq_ks<32>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
@@ -676,9 +699,10 @@ int launch_colfilter(const Run& r, int srcmode, float* bufW, float* bufO, const 
         (uint64_t)n * (uint64_t)C * 4u < (1ull << 31))
         return launch_boxt_spec(r, boxr_pick_ks(rad), srcData, srcFlags, dstW, dstO, n, C, rad, denom);
     if (srcmode == 2 && !deferred_denom && !transposed_out && weights_are_01 && boxq_pick_ks(rad) > 0 && rad <= 107 &&
-        // measured (1008 windows): K4r 13.4 / 19.1 / 21.9 / 22.2 / 20.0 / 23.0 / 23.7 ms at r = 21 / 32 / 33 / 36 / 40 / 43 / 54
-        // (r = 40: all 80 slots in registers, no LDS part), K4q 19.1 / 20.0 / 20.8 / 20.8 / 20.7 / 20.4 / 20.5
-        (g_boxq_override == 1 || (2 * rad >= BOXQ_MIN_2R && 2 * rad != 80)) &&
+        // measured (1008 windows, both images): K4r 13.4 / 13.5 / 14.6 / 15.9 / 19.2 / 21.9 / 19.9 / 23.0 / 23.7 ms at
+        // r = 17 / 21 / 27 / 28 / 32 / 35 / 40 / 43 / 54; K4q with blocks of 8 (four waves per SIMD, r <= 43)
+        // 15.3 / 15.8 / 16.0 / 15.9 / 16.1 / 16.3 / 17.2 / 17.3, with blocks of 16 19.3 ... 20.8
+        (g_boxq_override == 1 || 2 * rad >= BOXQ_MIN_2R) &&
         n % 4 == 0 && (uint64_t)n * (uint64_t)C * 4u < (1ull << 31))
         return launch_boxq(r, boxq_pick_ks(rad), srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
     if (srcmode == 2 && !deferred_denom && !transposed_out && weights_are_01 && boxr_pick_ks_t(rad) > 0 &&
@@ -986,6 +1010,7 @@ int launch_boxf_ks(const Run& r, const float* srcW, const float* srcO, float* ds
 
 static int boxq_pick_ks(int rad);
 extern thread_local int g_boxq_override;
+extern thread_local int g_boxq_b8_override;
 // K4qf: the fused frequency stage as an eight-wave stage pipeline (kernels_boxpipe.hpp)
 #ifndef BOXQF_MIN_2R
 #define BOXQF_MIN_2R 34
@@ -994,7 +1019,7 @@ extern thread_local int g_boxq_override;
 #define BOXQF_B8_DEFAULT 1
 #endif
 #ifndef BOXQF_B8_MAX2R
-#define BOXQF_B8_MAX2R 56                // blocks of 8 positions below this delay (56: up to 48 registers; 72: up to 64)
+#define BOXQF_B8_MAX2R 88                // blocks of 8 positions below this delay (56: up to 48 registers; 72: up to 64; 88: up to 80)
 #endif
 template <int KS, int MODE, int B = 16>
 int launch_boxqf_ks(const Run& r, const float* srcW, unsigned gap, float* dstW, float* dstO, const float* data,
@@ -1023,7 +1048,7 @@ int launch_boxf(const Run& r, int ks, const float* srcW, const float* srcO, floa
             const unsigned gap = (unsigned)(srcO - srcW);
             // blocks of 8 positions (two workgroups per CU) while the delay line leaves the registers for it
             static const int b8 = [] { const char* e = getenv("TRI_FILTER_PIPE_F_B8"); return e ? atoi(e) : BOXQF_B8_DEFAULT; }();
-            if (b8 && 2 * rad >= 32 && 2 * rad < BOXQF_B8_MAX2R) {
+            if (b8 && g_boxq_b8_override != 0 && 2 * rad >= 32 && 2 * rad < BOXQF_B8_MAX2R) {
                 switch (2 * rad / 8 * 8) {
                     case 32: return launch_boxqf_ks<32, MODE, 8>(r, srcW, gap, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
                     case 40: return launch_boxqf_ks<40, MODE, 8>(r, srcW, gap, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
@@ -1031,6 +1056,15 @@ int launch_boxf(const Run& r, int ks, const float* srcW, const float* srcO, floa
 #if BOXQF_B8_MAX2R > 56
                     case 56: return launch_boxqf_ks<56, MODE, 8>(r, srcW, gap, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
                     case 64: return launch_boxqf_ks<64, MODE, 8>(r, srcW, gap, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
+#endif
+#if BOXQF_B8_MAX2R > 72
+                    case 72: return launch_boxqf_ks<72, MODE, 8>(r, srcW, gap, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
+                    case 80:                                // (MODE 2 would spill 11 registers at 128: blocks of 16 for it)
+                        if (MODE == 1) return launch_boxqf_ks<80, 1, 8>(r, srcW, gap, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
+                        break;
+#endif
+#if BOXQF_B8_MAX2R > 88
+                    case 96: return launch_boxqf_ks<96, MODE, 8>(r, srcW, gap, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
 #endif
                 }
             }
@@ -1972,7 +2006,8 @@ extern "C" int tri_bench_boxfilter(const float* data, const uint8_t* flags4, flo
     if (n_win <= 0 || n_line <= 0 || n_col <= 0 || repeats <= 0 || n_win > 65535 || radius <= 0 || (stage != 2 && n_line % 4 != 0))
         return set_err(TRI_EINVAL, "bad shape");
     if (stage < 0 || stage > 2) return set_err(TRI_EUNSUPPORTED, "stage must be 0, 1 or 2");
-    if (variant < 0 || variant > 4 || (variant == 4 && stage != 1)) return set_err(TRI_EINVAL, "variant must be 0 .. 3 (4: exact row filter, stage 1 only)");
+    if (variant < 0 || variant > 5 || (variant == 4 && stage != 1) || (variant == 5 && stage == 2))
+        return set_err(TRI_EINVAL, "variant must be 0 .. 3 (4: exact row filter, stage 1 only; 5: stage pipeline with blocks of 16, stages 0 and 1)");
     if (stage == 2 && n_win != 1) return set_err(TRI_EINVAL, "the spectrum stage takes one window");
     Run r;
     r.st = (hipStream_t)stream;
@@ -1986,7 +2021,12 @@ extern "C" int tri_bench_boxfilter(const float* data, const uint8_t* flags4, flo
     // stage 2: 0 = the flagger's route, 1 = register rings, 2 / 3 = stage pipeline with blocks of 16 / 8
     if (stage == 2) { g_boxr_override = -1; g_boxp_override = variant == 0 ? -1 : (variant == 1 ? 0 : (variant == 2 ? 16 : 8)); }
     // stage 0: 0 = the flagger's route, 1 = LDS delay lines, 2 = register delay lines (K4r), 3 = stage pipeline (K4q)
-    if (stage == 0 || stage == 1) { g_boxq_override = variant == 0 ? -1 : (variant == 3 ? 1 : 0); if (variant == 3) g_boxr_override = -1; }
+    // (5 = the stage pipeline with blocks of 16 positions wherever 3 takes blocks of 8)
+    if (stage == 0 || stage == 1) {
+        g_boxq_override = variant == 0 ? -1 : (variant == 3 || variant == 5 ? 1 : 0);
+        if (variant == 3 || variant == 5) g_boxr_override = -1;
+        g_boxq_b8_override = variant == 5 ? 0 : -1;
+    }
     int rc = TRI_OK;
     // stage 1, variant 4: K4x works on rows -- the amplitudes are taken to the TF layout once (untimed), the rows it
     // writes go back to FT inside the timed loop (as in the flagger); out_w doubles as the row buffer.
@@ -2043,6 +2083,7 @@ extern "C" int tri_bench_boxfilter(const float* data, const uint8_t* flags4, flo
     g_boxr_override = -1;
     g_boxp_override = -1;
     g_boxq_override = -1;
+    g_boxq_b8_override = -1;
     if (rc) return rc;
     HIPCHK(hipEventRecord(e1, r.st));
     HIPCHK(hipEventSynchronize(e1));
