@@ -139,8 +139,12 @@ __device__ __forceinline__ float boxline_step(BoxLine<KS, V, A>& L, const int sl
 #define BOXR_WAVES_16 3                  // waves per SIMD the 8 / 16-slot forms are compiled for
 #endif
 #define BOXR_KS_MAX 80
-__host__ __device__ constexpr int boxr_pf(int ks) { return ks >= 64 ? 16 : (ks == 32 ? BOXR_PF_32 : BOXR_PF_SMALL); }
-__host__ __device__ constexpr int boxr_waves(int ks) { return ks <= 16 ? BOXR_WAVES_16 : (ks <= 32 ? BOXR_WAVES_32 : 1); }
+// (KS = 20: the whole delay line of r = 10 -- default.yaml's last time-axis radius -- in registers, no LDS part; blocks of 20 steps)
+#ifndef BOXR_WAVES_20
+#define BOXR_WAVES_20 2                  // (3: the data image's kernel spills 44 registers at 168 -- 44 ms instead of 11.7)
+#endif
+__host__ __device__ constexpr int boxr_pf(int ks) { return ks >= 64 ? 16 : (ks == 32 ? BOXR_PF_32 : (ks == 20 ? 20 : BOXR_PF_SMALL)); }
+__host__ __device__ constexpr int boxr_waves(int ks) { return ks <= 16 ? BOXR_WAVES_16 : (ks == 20 ? BOXR_WAVES_20 : (ks <= 32 ? BOXR_WAVES_32 : 1)); }
 #ifndef BOXR_WAVES_F32
 #define BOXR_WAVES_F32 2
 #endif

@@ -520,7 +520,14 @@ int boxr_pick_ks(int rad) {
 #ifndef BOXT_MIN_2R
 #define BOXT_MIN_2R 32
 #endif
-int boxr_pick_ks_t(int rad) { return 2 * rad >= BOXT_MIN_2R ? boxr_pick_ks(rad) : 0; }
+#ifndef BOXT_EXACT20
+#define BOXT_EXACT20 1                   // r = 10: all 20 slots of a delay line in registers (k_boxt<20, false, *>): no LDS traffic at all,
+                                         // 11.7 ms per 1008-window launch pair against 13.9 for the LDS delay lines (K4b)
+#endif
+int boxr_pick_ks_t(int rad) {
+    if (BOXT_EXACT20 && 2 * rad == 20) return boxr_pick_ks(rad) > 0 ? 20 : 0;
+    return 2 * rad >= BOXT_MIN_2R ? boxr_pick_ks(rad) : 0;
+}
 int boxr_pick_ks_f(int rad) {
     static const bool off = [] { const char* e = getenv("TRI_FILTER_NO_REGRING_F"); return e && e[0] == '1'; }();
     return off ? 0 : boxr_pick_ks(rad);
@@ -672,6 +679,7 @@ int launch_boxt(const Run& r, int ks, const float* srcData, const uint8_t* srcFl
                 int n, int C, int rad, float denom, size_t sws, size_t dws, int64_t W) {
     switch (ks) {
         case 16: return launch_boxt_ks<16>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
+        case 20: return launch_boxt_ks<20>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
         case 32: return launch_boxt_ks<32>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
         case 64: return launch_boxt_ks<64>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
         case 80: return launch_boxt_ks<80>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
