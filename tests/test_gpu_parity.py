@@ -166,7 +166,8 @@ def _time_stage(data, flags, radius, variant):
 @pytest.mark.parametrize("shape,radius", [((2, 64, 70), 8), ((1, 256, 64), 10), ((2, 1024, 130), 21), ((1, 512, 64), 32),
                                           ((2, 1024, 70), 43), ((1, 1024, 200), 54), ((1, 128, 64), 27), ((2, 64, 6), 15),
                                           ((1, 16, 64), 54), ((1, 2048, 64), 12), ((1, 256, 64), 28), ((1, 260, 70), 36),
-                                          ((2, 256, 64), 40), ((1, 128, 130), 16), ((1, 512, 64), 35)])
+                                          ((2, 256, 64), 40), ((1, 128, 130), 16), ((1, 512, 64), 35), ((1, 512, 64), 45),
+                                          ((1, 256, 70), 47), ((2, 512, 64), 52), ((1, 300, 64), 55), ((1, 64, 64), 44)])
 def test_time_stage_routes(gpu, shape, radius):
     """Time-axis stage of the 2-D background filter: LDS delay lines (variant 1), register delay lines K4r (2), the
     four-wave stage pipeline K4q with blocks of 8 where they apply (3) and of 16 throughout (5) and the flagger's own

@@ -227,7 +227,7 @@ k_boxp_spec(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFl
 // stages / stores positions 4w .. 4w + 3 of column l: one flag word covers them.
 // grid (ceil(C / 64), W), block 256; host: n % 4 == 0, window below 2^31 bytes, 16 <= 2r, 2r - KS < 16.
 // ---------------------------------------------------------------------------
-__host__ __device__ constexpr size_t boxq_lds_bytes(int B) { return (size_t)(4 * 4 * B * 64 + 2 * B * 64) * 4; }
+__host__ __device__ constexpr size_t boxq_lds_bytes(int B, int NF = 3) { return (size_t)(4 * (NF + 1) * B * 64 + 2 * B * 64) * 4; }
 #define BOXQ_LDS_BYTES boxq_lds_bytes(16)   // 72 KB: two workgroups per compute unit (B = 8: 36 KB, four)
 __host__ __device__ constexpr int boxq_prefetch(int ks) { return ks == 48 || ks == 96 ? 6 : (ks == 80 ? 5 : 4); }
 #ifndef BOXQ_ABLATE
@@ -244,7 +244,9 @@ __host__ __device__ constexpr int boxq_prefetch8(int nblk) {
     return nblk == 6 ? 3 : (nblk == 8 ? 4 : (nblk == 9 ? 3 : (nblk == 10 ? 2 : (nblk == 12 ? 4 : nblk))));
 }
 
-template <int IMG, int KS, int P, int B = 16>
+// NF: blocks a stage FIFO holds (+ a mirror of the first).  3 serves a FIFO delay d < B; 4 serves d < 2 B (the block
+// being written, the one being read and the two before it): blocks of 8 positions for 2r - KS < 16.
+template <int IMG, int KS, int P, int B = 16, int NF = 3>
 __device__ __forceinline__ void boxq_body(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags,
                                           float* __restrict__ dst, const int n, const int C, const int r, const BoxDenom denom,
                                           const size_t sws, const size_t dws, const size_t win) {
@@ -257,14 +259,14 @@ __device__ __forceinline__ void boxq_body(const float* __restrict__ srcData, con
     static_assert(KS % B == 0 && KS >= B, "register part: whole blocks");
     static_assert(B == 8 || B == 16, "block length");
     extern __shared__ float cf_ring[];                         // dynamic LDS: BOXQ_LDS_BYTES
-    typedef V FifoT[4 * B][64];                                // one stage's input stream: 3 blocks + mirror of the first
+    typedef V FifoT[(NF + 1) * B][64];                         // one stage's input stream: NF blocks + mirror of the first
     typedef float OutT[B][64];
     FifoT* fifo = reinterpret_cast<FifoT*>(cf_ring);           // [4]
-    OutT* outb = reinterpret_cast<OutT*>(cf_ring + 4 * 4 * B * 64);   // [2] output blocks of stage 4
+    OutT* outb = reinterpret_cast<OutT*>(cf_ring + 4 * (NF + 1) * B * 64);   // [2] output blocks of stage 4
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int R2 = 2 * r;
-    const int d = R2 - KS;                                     // host: 0 <= d < 16
+    const int d = R2 - KS;                                     // host: 0 <= d < B (NF = 3), < 2 B (NF = 4)
     const int c = blockIdx.x * 64 + lane;
     const bool colok = c < C;
     const int NB = (n + 4 * r + B - 1) / B;                    // every stage runs over t in [0, n + 4r)
@@ -273,7 +275,7 @@ __device__ __forceinline__ void boxq_body(const float* __restrict__ srcData, con
     const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)(srcData + win * sws), 0, (int)((unsigned)n * rowb), 0x00020000);
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)(dst + win * dws), 0, (int)((unsigned)n * rowb), 0x00020000);
     const unsigned coff = (unsigned)c * 4u;
-    for (int k = tid; k < 4 * 4 * B * 64; k += 256) reinterpret_cast<V*>(cf_ring)[k] = 0;
+    for (int k = tid; k < 4 * (NF + 1) * B * 64; k += 256) reinterpret_cast<V*>(cf_ring)[k] = 0;
 
     unsigned pref[P];                                          // TF4 word: flags of positions 4w .. 4w + 3
     float prex[IMG == 1 ? P : 1][PPT];
@@ -295,8 +297,8 @@ __device__ __forceinline__ void boxq_body(const float* __restrict__ srcData, con
     for (int k = 0; k < KS; k++) R[k] = 0;
     A acc = 0;
     int lslot = 0;                                             // FIFO block slot the staging writes next
-    int slot = 0, s0 = 3 * B - d;                              // this wave's input block slot / first row of the delayed window
-    if (s0 >= 3 * B) s0 -= 3 * B;
+    int slot = 0, s0 = NF * B - d;                             // this wave's input block slot / first row of the delayed window
+    if (s0 >= NF * B) s0 -= NF * B;
     // a stage's output is masked where the NEXT stage does not take it (see boxline_step):
     // stage 2 takes out_1[t] for t < n + 2r, stage 4 takes out_3[t] for t >= 2r
     const int keep_lo = wave == 2 ? R2 : 0;
@@ -326,9 +328,9 @@ __device__ __forceinline__ void boxq_body(const float* __restrict__ srcData, con
                 for (int k = 0; k < PPT; k++) p[k * 64] = sv[k];
                 if (lslot == 0) {
 #pragma unroll
-                    for (int k = 0; k < PPT; k++) p[(3 * B + k) * 64] = sv[k];
+                    for (int k = 0; k < PPT; k++) p[(NF * B + k) * 64] = sv[k];
                 }
-                lslot = lslot == 2 ? 0 : lslot + 1;
+                lslot = lslot == NF - 1 ? 0 : lslot + 1;
             }
             issue(j + P, q);                                   // fetch block j + P (always issued)
 #endif
@@ -368,11 +370,11 @@ __device__ __forceinline__ void boxq_body(const float* __restrict__ srcData, con
                     }
                     if (slot == 0) {
 #pragma unroll
-                        for (int u = 0; u < B; u++) po[(3 * B + u) * 64] = o[u];
+                        for (int u = 0; u < B; u++) po[(NF * B + u) * 64] = o[u];
                     }
                 }
-                slot = slot == 2 ? 0 : slot + 1;
-                s0 = s0 + B >= 3 * B ? s0 + B - 3 * B : s0 + B;
+                slot = slot == NF - 1 ? 0 : slot + 1;
+                s0 = s0 + B >= NF * B ? s0 + B - NF * B : s0 + B;
             }
 #endif
 #if !(BOXQ_ABLATE & 1)
@@ -411,6 +413,15 @@ __global__ void __launch_bounds__(256, B == 8 ? 4 : 2)
 k_boxq(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags, float* __restrict__ dstImg,
        int n, int C, int r, BoxDenom denom, size_t sws, size_t dws) {
     boxq_body<IMG, KS, B == 8 ? boxq_prefetch8(KS / 8) : boxq_prefetch(KS), B>(srcData, srcFlags, dstImg, n, C, r, denom, sws, dws, blockIdx.y);
+}
+// Delay lines of 96 registers (r = 52 ... 55, default.yaml's largest time-axis radius 54): blocks of 8 with FIFOs one block
+// deeper (8 <= 2r - KS < 16; 44 KB of LDS) and 168 registers: THREE workgroups = three waves per SIMD instead of the
+// two that blocks of 16 allow.  host: 8 <= 2r - KS < 16
+template <int KS, int IMG>
+__global__ void __launch_bounds__(256, 3)
+k_boxq_deep(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFlags, float* __restrict__ dstImg,
+            int n, int C, int r, BoxDenom denom, size_t sws, size_t dws) {
+    boxq_body<IMG, KS, boxq_prefetch8(KS / 8), 8, 4>(srcData, srcFlags, dstImg, n, C, r, denom, sws, dws, blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------

@@ -653,8 +653,33 @@ static int boxq_pick_ks8(int rad) {
     return 2 * rad / 8 * 8;
 }
 
+// blocks of 8 with FIFOs one block deeper (k_boxq_deep): KS = 80 for 2r = 88 .. 95, KS = 96 for 2r = 104 .. 111
+template <int KS>
+int launch_boxq_deep(const Run& r, const float* srcData, const uint8_t* srcFlags, float* dstW, float* dstO,
+                     int n, int C, int rad, float denom, size_t sws, size_t dws, int64_t W) {
+    const hipError_t attr = [] {
+        hipError_t e = lds_optin(reinterpret_cast<const void*>(&k_boxq_deep<KS, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = lds_optin(reinterpret_cast<const void*>(&k_boxq_deep<KS, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return e;
+    }();
+    HIPCHK(attr);
+    dim3 grid((unsigned)cdiv(C, 64), (unsigned)W);
+    const BoxDenom dn = box_reciprocal(denom);
+    hipLaunchKernelGGL((k_boxq_deep<KS, 0>), grid, dim3(256), boxq_lds_bytes(8, 4), r.st, srcData, srcFlags, dstW, n, C, rad, dn, sws, dws);
+    hipLaunchKernelGGL((k_boxq_deep<KS, 1>), grid, dim3(256), boxq_lds_bytes(8, 4), r.st, srcData, srcFlags, dstO, n, C, rad, dn, sws, dws);
+    LAUNCHCHK();
+    return TRI_OK;
+}
+#ifndef BOXQ_DEEP
+#define BOXQ_DEEP 1
+#endif
+
 int launch_boxq(const Run& r, int ks, const float* srcData, const uint8_t* srcFlags, float* dstW, float* dstO,
                 int n, int C, int rad, float denom, size_t sws, size_t dws, int64_t W) {
+    if (BOXQ_DEEP && boxq_pick_ks8(40) > 0) {              // (blocks of 8 not switched off)
+        if (2 * rad >= 88 && 2 * rad < 96) return launch_boxq_deep<80>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
+        if (2 * rad >= 104 && 2 * rad < 112) return launch_boxq_deep<96>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
+    }
     switch (boxq_pick_ks8(rad)) {
         case 32: return launch_boxq_ks<32, 8>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
         case 40: return launch_boxq_ks<40, 8>(r, srcData, srcFlags, dstW, dstO, n, C, rad, denom, sws, dws, W);
