@@ -208,7 +208,8 @@ def _freq_stage(wimg, oimg, data, radius, variant):
 @pytest.mark.parametrize("shape,radius", [((2, 64, 128), 8), ((1, 72, 256), 10), ((2, 132, 1024), 21), ((1, 64, 512), 32),
                                           ((2, 36, 1024), 43), ((1, 200, 1024), 54), ((1, 64, 128), 27), ((1, 8, 64), 17),
                                           ((1, 64, 16), 54), ((1, 72, 256), 34), ((1, 64, 512), 38), ((2, 64, 256), 40),
-                                          ((1, 132, 512), 30), ((1, 64, 512), 46)])
+                                          ((1, 132, 512), 30), ((1, 64, 512), 46), ((1, 64, 256), 13), ((2, 68, 128), 15),
+                                          ((1, 64, 300), 12)])
 def test_frequency_stage_routes(gpu, shape, radius):
     """Frequency-axis stage fused with the masked division: LDS delay lines (variant 1), register delay lines
     K4r (2), the eight-wave stage pipeline K4qf with blocks of 8 where they apply (3) and of 16 throughout (5) and the

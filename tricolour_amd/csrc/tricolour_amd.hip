@@ -1048,6 +1048,9 @@ extern thread_local int g_boxq_b8_override;
 #ifndef BOXQF_MIN_2R
 #define BOXQF_MIN_2R 34
 #endif
+#ifndef BOXQF_FEW_WAVES
+#define BOXQF_FEW_WAVES 2048             // waves a K4r launch needs to fill the machine at two per SIMD
+#endif
 #ifndef BOXQF_B8_DEFAULT
 #define BOXQF_B8_DEFAULT 1
 #endif
@@ -1074,15 +1077,20 @@ int launch_boxf(const Run& r, int ks, const float* srcW, const float* srcO, floa
     {
         static const bool off = [] { const char* e = getenv("TRI_FILTER_NO_PIPE_F"); return e && e[0] == '1'; }();
         const int kq = boxq_pick_ks(rad);
-        const bool want = g_boxq_override == 1 || (g_boxq_override < 0 && !off && 2 * rad >= BOXQF_MIN_2R);
+        // Few, long lines (an SKA slab: 64 windows of 512 lines x 65536 channels): the one-wave-per-32-lines kernels (K4r) fill
+        // half the machine at best; the stage pipeline (a workgroup of eight waves per 64 lines) then takes the small radii too.
+        const bool few = (int64_t)W * cdiv(C, 32) < BOXQF_FEW_WAVES;
+        const bool want = g_boxq_override == 1 || (g_boxq_override < 0 && !off && (2 * rad >= BOXQF_MIN_2R || (few && 2 * rad >= 16)));
         if (want && kq > 0 && srcO > srcW && n % 4 == 0 && ld % 4 == 0 && sws_img % 4 == 0 && (uint64_t)(srcO - srcW) % 4 == 0 &&
             ((uintptr_t)srcW % 16 == 0) && ((uint64_t)(srcO - srcW) + (uint64_t)C * ld) * 4u < (1ull << 31) &&
             (uint64_t)n * (uint64_t)C * 4u < (1ull << 31)) {
             const unsigned gap = (unsigned)(srcO - srcW);
             // blocks of 8 positions (two workgroups per CU) while the delay line leaves the registers for it
             static const int b8 = [] { const char* e = getenv("TRI_FILTER_PIPE_F_B8"); return e ? atoi(e) : BOXQF_B8_DEFAULT; }();
-            if (b8 && g_boxq_b8_override != 0 && 2 * rad >= 32 && 2 * rad < BOXQF_B8_MAX2R) {
+            if (b8 && g_boxq_b8_override != 0 && 2 * rad >= 16 && 2 * rad < BOXQF_B8_MAX2R) {
                 switch (2 * rad / 8 * 8) {
+                    case 16: return launch_boxqf_ks<16, MODE, 8>(r, srcW, gap, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
+                    case 24: return launch_boxqf_ks<24, MODE, 8>(r, srcW, gap, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
                     case 32: return launch_boxqf_ks<32, MODE, 8>(r, srcW, gap, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
                     case 40: return launch_boxqf_ks<40, MODE, 8>(r, srcW, gap, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
                     case 48: return launch_boxqf_ks<48, MODE, 8>(r, srcW, gap, dstW, dstO, data, n, C, ld, rad, sws_img, dws, ws_data, W, nanflag);
