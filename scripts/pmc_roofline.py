@@ -58,7 +58,7 @@ for e in roof:
         emit("sumthreshold", e, ["k_colst_mask"], "dword-per-lane row loads (x2 on FETCH_SIZE, calibrated in round 1 on this kernel's known byte count), byte stores")
     elif "time-axis" in k:
         rad = int(k.rsplit("r = ", 1)[1])
-        pats = ["k_boxq<"] if 72 <= 2 * rad < 112 else (["k_boxt"] if rad >= 16 else ["k_colfilter_lds<2"])
+        pats = (["k_boxq_deep<"] if (88 <= 2 * rad < 96 or 104 <= 2 * rad < 112) else ["k_boxq<"]) if 56 <= 2 * rad < 112 else (["k_boxt"] if rad >= 16 else ["k_colfilter_lds<2"])
         emit("boxfilter_s0_r%d" % rad, e, pats, "one launch per image (weight: packed flag words in, float32 out; data: + float32 in); dword-per-lane accesses")
     elif "frequency-axis" in k:
         rad = int(k.rsplit("r = ", 1)[1])

@@ -167,7 +167,8 @@ def _time_stage(data, flags, radius, variant):
                                           ((2, 1024, 70), 43), ((1, 1024, 200), 54), ((1, 128, 64), 27), ((2, 64, 6), 15),
                                           ((1, 16, 64), 54), ((1, 2048, 64), 12), ((1, 256, 64), 28), ((1, 260, 70), 36),
                                           ((2, 256, 64), 40), ((1, 128, 130), 16), ((1, 512, 64), 35), ((1, 512, 64), 45),
-                                          ((1, 256, 70), 47), ((2, 512, 64), 52), ((1, 300, 64), 55), ((1, 64, 64), 44)])
+                                          ((1, 256, 70), 47), ((2, 512, 64), 52), ((1, 300, 64), 55), ((1, 64, 64), 44), ((1, 256, 64), 50),
+                                          ((1, 512, 64), 58)])
 def test_time_stage_routes(gpu, shape, radius):
     """Time-axis stage of the 2-D background filter: LDS delay lines (variant 1), register delay lines K4r (2), the
     four-wave stage pipeline K4q with blocks of 8 where they apply (3) and of 16 throughout (5) and the flagger's own
