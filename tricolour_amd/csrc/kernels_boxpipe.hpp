@@ -226,6 +226,13 @@ k_boxp_spec(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFl
 // wave s runs stage s + 1 over block j - s - 1, everybody stores block j - 5.  Thread (wave w, lane l)
 // stages / stores positions 4w .. 4w + 3 of column l: one flag word covers them.
 // grid (ceil(C / 64), W), block 256; host: n % 4 == 0, window below 2^31 bytes, 16 <= 2r, 2r - KS < 16.
+//
+// Round 3: the block length B is a template parameter.  What bounds these kernels is OCCUPANCY (one barrier per block,
+// dependent float64 chains: only other resident waves fill the gaps), so wherever the delay line leaves room the kernel is
+// compiled for 128 registers and runs blocks of EIGHT positions -- 36 KB of FIFOs, four workgroups = four waves per SIMD,
+// KS = 8 * floor(2r / 8) <= 80, 2r - KS < 8, a thread stages / stores two positions (half a TF4 flag word): 15.3-17.3 ms per
+// 1008-window launch pair against 19.3-20.8 with blocks of 16.  k_boxq_deep (KS = 80 / 96 with 8 <= 2r - KS < 16): blocks of 8
+// with FIFOs of FOUR blocks + mirror and 168 registers, three waves per SIMD.
 // ---------------------------------------------------------------------------
 __host__ __device__ constexpr size_t boxq_lds_bytes(int B, int NF = 3) { return (size_t)(4 * (NF + 1) * B * 64 + 2 * B * 64) * 4; }
 #define BOXQ_LDS_BYTES boxq_lds_bytes(16)   // 72 KB: two workgroups per compute unit (B = 8: 36 KB, four)
