@@ -311,7 +311,9 @@ __device__ __forceinline__ Sel3State select3(unsigned* hist, unsigned* sh, ENUM&
 // ("TF4": word (q, c) holds the flag bytes of rows 4q .. 4q + 3 at column c, rows of tf_ld words).  That is what the
 // rejection loop has when the exact row filter (K4x) leaves |data - background| as rows: the block median is taken
 // where the rows lie, no transpose to the FT slab.  The select itself is the same (any enumeration order selects exactly).
-template <bool VEC, bool TFB = false>
+// UNR: 16-byte groups a thread keeps in flight while it streams a segment (VEC).  4 where the launch fills the machine
+// with workgroups; 16 for few, long segments (an SKA slab's 640 block medians of 3.4 M samples each: 3.9 -> 3.2 ms).
+template <bool VEC, bool TFB = false, int UNR = MED2_UNROLL>
 __global__ void __launch_bounds__(256)
 k_median2(const float* __restrict__ data, const uint8_t* __restrict__ flags,
           double* __restrict__ med, size_t WSd, size_t WSf, size_t RS, size_t ES,
@@ -391,17 +393,17 @@ k_median2(const float* __restrict__ data, const uint8_t* __restrict__ flags,
             };
             if (tid == 0 && n4 > 0) edge(0);
             if (tid == 1 && n4 > 1) edge(n4 - 1);
-            // MED2_UNROLL 16-byte groups in flight per thread: the segment streams from HBM once
+            // UNR 16-byte groups in flight per thread: the segment streams from HBM once
             // (pass 1) and from L2 / Infinity Cache afterwards
             const int64_t hi4 = n4 - 1;                          // interior groups: [1, n4 - 1)
             int64_t i = 1 + tid;
-            for (; i + 256 * (MED2_UNROLL - 1) < hi4; i += 256 * MED2_UNROLL) {
-                float4 dv[MED2_UNROLL];
-                uchar4 fv[MED2_UNROLL];
+            for (; i + 256 * (UNR - 1) < hi4; i += 256 * UNR) {
+                float4 dv[UNR];
+                uchar4 fv[UNR];
 #pragma unroll
-                for (int q = 0; q < MED2_UNROLL; q++) { dv[q] = d4[i + 256 * q]; fv[q] = f4[i + 256 * q]; }
+                for (int q = 0; q < UNR; q++) { dv[q] = d4[i + 256 * q]; fv[q] = f4[i + 256 * q]; }
 #pragma unroll
-                for (int q = 0; q < MED2_UNROLL; q++) {
+                for (int q = 0; q < UNR; q++) {
                     if (!fv[q].x) visit(__float_as_uint(dv[q].x) & 0x7FFFFFFFu);
                     if (!fv[q].y) visit(__float_as_uint(dv[q].y) & 0x7FFFFFFFu);
                     if (!fv[q].z) visit(__float_as_uint(dv[q].z) & 0x7FFFFFFFu);

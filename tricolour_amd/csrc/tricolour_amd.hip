@@ -436,7 +436,10 @@ int launch_median(const Run& r, const float* data, const uint8_t* flags, double*
             // scratch for the predicted-window candidates (K3c): one read of the segment instead of two
             static const bool no_predict = [] { const char* e = getenv("TRI_MEDIAN_NO_PREDICT"); return e && e[0] == '1'; }();
             if (no_predict || cand_cap < max_len || cand_ws % 4 != 0 || cand_cap % 4 != 0 || ((uintptr_t)gcand % 16 != 0)) { gcand = nullptr; cand_ws = 0; cand_cap = 0; }
-            if (vec_ok || row4)
+            // few, long segments (fewer workgroups than the machine holds at six per CU): sixteen 16-byte groups in flight per thread
+            if ((vec_ok || row4) && (int64_t)R * G * W < 1536 && max_len >= (int64_t)1 << 20)
+                hipLaunchKernelGGL((k_median2<true, false, 16>), grid, dim3(256), 0, r.st, data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G, gcand, cand_ws, cand_cap);
+            else if (vec_ok || row4)
                 hipLaunchKernelGGL(k_median2<true>, grid, dim3(256), 0, r.st, data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G, gcand, cand_ws, cand_cap);
             else
                 hipLaunchKernelGGL(k_median2<false>, grid, dim3(256), 0, r.st, data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G, gcand, cand_ws, cand_cap);
