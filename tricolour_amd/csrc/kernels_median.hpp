@@ -445,6 +445,27 @@ k_median2(const float* __restrict__ data, const uint8_t* __restrict__ flags,
     {
         unsigned kmin = 0xFFFFFFFFu, kmax = 0;
         const int64_t stride = len / 2048 > 0 ? len / 2048 : 1;
+        // Long contiguous segments with a candidate buffer (the prediction pass below applies): the range comes from the SAME 64 runs
+        // of 256 consecutive samples the prediction histograms afterwards (they are then in L2) -- 2048 single samples 820 bytes
+        // apart cost a 128-byte line each for data and flags: a quarter of the segment's bytes (6.95 B read per sample for 5.2).
+        const bool range_from_runs = gcand != nullptr && len >= 65536 && (ES == 1 || TFB);
+        if (range_from_runs) {
+            const int64_t rstep0 = len / 64;
+#pragma unroll 8
+            for (int rr = 0; rr < 64; rr++) {
+                unsigned k;
+                bool ok;
+                if (TFB) {
+                    const int T = 4 * tf_T4;
+                    ok = tid < tf_cl && tf_key_tc((int)(((int64_t)rr * T) >> 6), tid, k);
+                } else {
+                    const int64_t i = rr * rstep0 + tid;
+                    ok = !flags[i];
+                    k = __float_as_uint(data[i]) & 0x7FFFFFFFu;
+                }
+                if (ok) { kmin = min(kmin, k); kmax = max(kmax, k); }
+            }
+        } else
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int64_t i = (int64_t)(j * 256 + tid) * stride;
