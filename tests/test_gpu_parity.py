@@ -1002,6 +1002,27 @@ def test_random_cases_vs_oracle(gpu, oracle, block):
             block, k, vis.shape, kw, int((out != exp).sum()))
 
 
+def test_large_windows_random_kwargs_vs_oracle(gpu, oracle):
+    """Windows of the production sizes with RANDOM spike widths / iteration counts (radii 2 ... 64 on both axes): every
+    radius class of the filter routes -- register delay lines, stage pipelines with blocks of 8 / 16 and the deep FIFOs,
+    LDS delay lines -- against the oracle at line lengths the small random cases do not reach."""
+    rs = np.random.RandomState(777)
+    for case in range(8):
+        t, f = [(1024, 4096), (512, 2048), (1024, 1024), (256, 8192)][case % 4]
+        shape = (2, 1, t, f)
+        kw = dict(background_iterations=int(rs.randint(1, 6)), spike_width_time=float(rs.uniform(3, 14)),
+                  spike_width_freq=float(rs.uniform(3, 12)), num_major_iterations=int(rs.randint(1, 3)),
+                  background_reject=float(rs.choice([2.0, 3.0])), freq_chunks=int(rs.choice([4, 10])))
+        vis = (rs.standard_normal(shape) + 1j * rs.standard_normal(shape)).astype(np.complex64)
+        vis[..., rs.randint(0, f, 8)] *= 6
+        vis[:, :, rs.randint(0, t, 4), :] += 4
+        vis[rs.uniform(size=shape) < 1e-4] = np.nan
+        flags = rs.uniform(size=shape) < 0.03
+        exp = oracle.sum_threshold_flagger(vis, flags, **kw)
+        out = gpu.sum_threshold_flagger(vis, flags, **kw)
+        assert np.array_equal(out, exp), "case %d shape %s kw %s: %d flags differ" % (case, shape, kw, int((out != exp).sum()))
+
+
 ALT_PATH_SCRIPT = r'''
 import sys
 sys.path.insert(0, %r)
