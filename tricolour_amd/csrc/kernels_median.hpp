@@ -941,7 +941,11 @@ __global__ void __launch_bounds__(256)
 k_median_wave(const float* __restrict__ data, const uint8_t* __restrict__ flags,
               double* __restrict__ med, size_t WSd, size_t WSf, size_t RS, size_t ES,
               const int64_t* __restrict__ seg_start, const int64_t* __restrict__ seg_len,
-              int R, int G) {
+              int R, int G, const uint8_t* __restrict__ flags2 = nullptr, const uint8_t* __restrict__ colflags = nullptr,
+              size_t WScol = 0) {
+    // flags2 (optional): a second flag image of the same layout, OR-ed in on the fly; colflags (optional, ES == 1): one flag
+    // per column of the rows (a window's spectrum flags, WScol bytes per window) -- the frequency-axis MAD of
+    // flagging.py:967-969 sees flags | time_flags | spec_flags without a pass that writes the union first.
     __shared__ unsigned hist[4][256];
     const unsigned SENT = 0xFFFFFFFFu;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -953,6 +957,8 @@ k_median_wave(const float* __restrict__ data, const uint8_t* __restrict__ flags,
     const size_t rel = (size_t)row * RS + (size_t)seg_start[g] * ES;
     const float* d = data + win * WSd + rel;
     const uint8_t* f = flags + win * WSf + rel;
+    const uint8_t* f2 = flags2 ? flags2 + win * WSf + rel : nullptr;
+    const uint8_t* cf = colflags ? colflags + win * WScol + (live ? (size_t)seg_start[g] : (size_t)0) : nullptr;
     unsigned keys[KS];
     unsigned nloc = 0;
     if (VEC4) {
@@ -969,7 +975,10 @@ k_median_wave(const float* __restrict__ data, const uint8_t* __restrict__ flags,
             uchar4 fv = make_uchar4(1, 1, 1, 1);
             if (i < len + mis) {
                 dv = *reinterpret_cast<const float4*>(d4 + i);
-                fv = *reinterpret_cast<const uchar4*>(f4 + i);
+                unsigned fw = *reinterpret_cast<const unsigned*>(f4 + i);
+                if (f2) fw |= *reinterpret_cast<const unsigned*>(f2 - mis + i);
+                if (cf) fw |= *reinterpret_cast<const unsigned*>(cf - mis + i);
+                fv = make_uchar4((unsigned char)(fw & 0xFFu), (unsigned char)((fw >> 8) & 0xFFu), (unsigned char)((fw >> 16) & 0xFFu), (unsigned char)(fw >> 24));
             }
             const int j = i - mis;                         // logical index of the group's first sample
             const bool v0 = j >= 0 && j < len && !fv.x;
@@ -989,7 +998,7 @@ k_median_wave(const float* __restrict__ data, const uint8_t* __restrict__ flags,
             unsigned k = SENT;
             if (i < len) {
                 size_t a = (size_t)i * ES;
-                if (!f[a]) { k = __float_as_uint(d[a]) & 0x7FFFFFFFu; nloc++; }
+                if (!f[a] && !(f2 && f2[a]) && !(cf && cf[i])) { k = __float_as_uint(d[a]) & 0x7FFFFFFFu; nloc++; }
             }
             keys[u] = k;
         }

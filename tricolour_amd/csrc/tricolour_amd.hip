@@ -400,12 +400,20 @@ bool st_use_mask(int L, int C) {
     return !force_register && (uint64_t)L * (uint64_t)C * 4u < (1ull << 31);   // signed 32-bit scalar offsets
 }
 
+// launch_median() can OR a second flag image and per-column flags into the flags it reads when the segments fit the wave kernels
+static bool median_takes_extra_flags(int64_t max_len) { return max_len <= 64 * MW_K; }
+
 int launch_median(const Run& r, const float* data, const uint8_t* flags, double* med, size_t WSd,
                   size_t WSf, size_t RS, size_t ES, const int64_t* seg_start,
                   const int64_t* seg_len, int R, int G, int64_t W, int64_t max_len, bool vec_ok = false,
                   bool rows_aligned = false, bool segs_aligned = false,
-                  unsigned* gcand = nullptr, size_t cand_ws = 0, unsigned cand_cap = 0) {
+                  unsigned* gcand = nullptr, size_t cand_ws = 0, unsigned cand_cap = 0,
+                  const uint8_t* flags2 = nullptr, const uint8_t* colflags = nullptr, size_t WScol = 0) {
     if ((int64_t)R * G <= 0 || W <= 0) return TRI_OK;
+    // (extra flag sources: the wave kernels only -- see median_takes_extra_flags())
+    if ((flags2 || colflags) && (max_len > 64 * MW_K || (colflags && ES != 1) || ((uintptr_t)flags2 % 4 != 0) ||
+                                 ((uintptr_t)colflags % 4 != 0) || WScol % 4 != 0))
+        return set_err(TRI_EUNSUPPORTED, "extra flag sources need wave-sized segments of contiguous, 4-byte aligned rows");
     if ((int64_t)R * G > 0x7FFFFFFF || W > 65535) return set_err(TRI_EUNSUPPORTED, "median grid too large");
     // segments of contiguous 4-aligned rows can be loaded 16 bytes at a time
     // (misaligned segment ends are masked, costing up to 3 extra slots)
@@ -414,16 +422,16 @@ int launch_median(const Run& r, const float* data, const uint8_t* flags, double*
     const int64_t slack = segs_aligned ? 0 : 3;   // misaligned segment starts cost up to 3 masked slots
     if (max_len + slack <= 64 * 8 && row4)
         hipLaunchKernelGGL((k_median_wave<8, true>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)W), dim3(256), 0, r.st,
-                           data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
+                           data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G, flags2, colflags, WScol);
     else if (max_len <= 64 * 8)
         hipLaunchKernelGGL((k_median_wave<8, false>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)W), dim3(256), 0, r.st,
-                           data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
+                           data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G, flags2, colflags, WScol);
     else if (max_len + slack <= 64 * MW_K && row4)
         hipLaunchKernelGGL((k_median_wave<MW_K, true>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)W), dim3(256), 0, r.st,
-                           data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
+                           data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G, flags2, colflags, WScol);
     else if (max_len <= 64 * MW_K)
         hipLaunchKernelGGL((k_median_wave<MW_K, false>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)W), dim3(256), 0, r.st,
-                           data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G);
+                           data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G, flags2, colflags, WScol);
     else {
         // long segments: two-pass select (K3c); TRI_MEDIAN_3PASS=1 keeps the three-pass kernel (A/B runs, tests)
         static const bool three = [] { const char* e = getenv("TRI_MEDIAN_3PASS"); return e && e[0] == '1'; }();
@@ -1645,15 +1653,24 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
 
     // flagging.py:967-969  flags |= time_flags; SumThreshold along frequency.
     // MAD per (time, chunk) = contiguous row segments of the TF layout.
-    if (defer_tf) {
-        hipLaunchKernelGGL(k_or_spec_more16, grid1(N / 16, W), dim3(256), 0, r.st, ws.flagsTF, ws.srows, ws.tflTF, T, Fa / 16);
-        LAUNCHCHK();
+    // (the union is read by this MAD only -- the next major iteration rebuilds the TF flags -- so when the chunk medians are
+    //  wave medians they take the three sources as they are and no pass writes the union; TRI_NO_FUSED_OR=1: the pass)
+    static const bool no_fused_or = [] { const char* e = getenv("TRI_NO_FUSED_OR"); return e && e[0] == '1'; }();
+    if (defer_tf && !no_fused_or && median_takes_extra_flags(pl.maxchunk) && Fa % 4 == 0) {
+        rc = launch_median(r, residTF, ws.flagsTF, ws.med, N, N, (size_t)Fa, 1, ws.segC_start, ws.segC_len, T, G, W, pl.maxchunk, false, Fa % 4 == 0,
+                           false, nullptr, 0, 0, ws.tflTF, ws.srows, (size_t)Fa);
+        if (rc) return rc;
     } else {
-        rc = launch_u8<1>(r, ws.tflTF, ws.flagsTF, N, N, N, W);
+        if (defer_tf) {
+            hipLaunchKernelGGL(k_or_spec_more16, grid1(N / 16, W), dim3(256), 0, r.st, ws.flagsTF, ws.srows, ws.tflTF, T, Fa / 16);
+            LAUNCHCHK();
+        } else {
+            rc = launch_u8<1>(r, ws.tflTF, ws.flagsTF, N, N, N, W);
+            if (rc) return rc;
+        }
+        rc = launch_median(r, residTF, ws.flagsTF, ws.med, N, N, (size_t)Fa, 1, ws.segC_start, ws.segC_len, T, G, W, pl.maxchunk, false, Fa % 4 == 0);
         if (rc) return rc;
     }
-    rc = launch_median(r, residTF, ws.flagsTF, ws.med, N, N, (size_t)Fa, 1, ws.segC_start, ws.segC_len, T, G, W, pl.maxchunk, false, Fa % 4 == 0);
-    if (rc) return rc;
     rc = launch_colst(r, pl.swF, residFT, ws.med, ws.fflFT, ws.d_chunk_ends, Fa, T, G, wsB, N, W);
     if (rc) return rc;
     rc = launch_transpose<uint8_t>(r, ws.fflFT, ws.fflTF, Fa, T, N, N, W);
