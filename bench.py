@@ -30,7 +30,11 @@ Prints ONE JSON line (rank 0): metric / value = whole-job Mvis/s with inputs alr
   "parity_check"  the HIP path on the windows the cpu_baseline leg fed the oracle: {windows, vis, mismatches};
   "cpu_baseline"  the CPU oracle (a C restatement of the reference's numba path -- numba itself cannot run
                   here) on a bounded sample of the same workload on this box's host cores (rank 0, N=1);
-  "other_params"  the same slab with the other shipped parameter sets (slab workload, N=1).
+  "other_params"  the same slab with the other shipped parameter sets (slab workload, N=1);
+  "other_workloads"  short `chain` (configs[3]) and `ska` (configs[4], 1-GPU half) legs with their own parity_check,
+                  so that the one command the driver times carries every single-GPU configuration (slab workload, N=1).
+A parity_check that fails (any mismatch on a bit-exact leg, < 99.9 % agreement on the chain leg) is reported in the
+line ("parity_ok": false) and the process exits with code 4 after printing it.
 """
 import argparse
 import ctypes as C
@@ -137,9 +141,10 @@ def synth_host_windows(nwin, T, F, seed=1234):
     return vis, flags
 
 
-def cpu_baseline(kw, T, F, seconds_budget=25.0, chain=None):
+def cpu_baseline(kw, T, F, seconds_budget=25.0, chain=None, fixed_windows=None):
     """Oracle (C restatement of the reference CPU path, OpenMP over windows) on a bounded sample of the same
-    workload.  `chain`: also run the cheap steps and uvcontsub (numpy restatements) in front."""
+    workload.  `chain`: also run the cheap steps and uvcontsub (numpy restatements) in front.  `fixed_windows`: take
+    that many windows (capped at the usable cores) without the one-window calibration run."""
     from oracle import oracle
     oracle.set_modes(oracle.POW_SQMUL, oracle.INTERP_F64)
     nproc = os.cpu_count() or 1
@@ -176,14 +181,18 @@ def cpu_baseline(kw, T, F, seconds_budget=25.0, chain=None):
 
     # calibrate on one window with one thread, then size the sample: every thread gets the same number of
     # windows, the whole sample stays within ~seconds_budget of wall time and 128 windows (4.3 GB of vis)
-    vis, flags = synth_host_windows(1, T, F)
-    t1, _ = run(vis, flags, 1)
-    per_thread = max(1, min(2, int(seconds_budget / max(t1, 1e-3))))
-    nwin = cores * per_thread
-    while nwin > 128 and per_thread > 1:
-        per_thread -= 1
+    if fixed_windows:
+        nwin = max(1, min(int(fixed_windows), cores))
+        cores = nwin
+    else:
+        vis, flags = synth_host_windows(1, T, F)
+        t1, _ = run(vis, flags, 1)
+        per_thread = max(1, min(2, int(seconds_budget / max(t1, 1e-3))))
         nwin = cores * per_thread
-    nwin = min(nwin, 256)
+        while nwin > 128 and per_thread > 1:
+            per_thread -= 1
+            nwin = cores * per_thread
+        nwin = min(nwin, 256)
     vis, flags = synth_host_windows(nwin, T, F)
     dt, out = run(vis, flags, cores)
     what = "chain (flag_nans_zeros, uvcontsub, sum_threshold)" if chain is not None else "same kwargs"
@@ -211,23 +220,33 @@ def parity_check(torch, tricolour_amd, device, kw, vis, flags, expected, chain=N
     torch.cuda.synchronize()
     got = got.cpu().numpy()
     bad = int((got != expected).sum())
-    return dict(windows=int(vis.shape[0] * vis.shape[1]), vis=int(vis.size), mismatches=bad,
+    ok = bad == 0 if chain is None else bad <= 1e-3 * vis.size
+    return dict(windows=int(vis.shape[0] * vis.shape[1]), vis=int(vis.size), mismatches=bad, parity_ok=bool(ok),
                 flagged_oracle=int(expected.sum()), flagged_hip=int(got.sum()),
                 expected="bit-exact" if chain is None else ">= 99.9 % agreement (uvcontsub FFT order, SURVEY 8f-2)",
                 checker="oracle/ (C restatement of the reference numba path), same windows and kwargs as cpu_baseline")
 
 
-def _pmc_traffic(name, samples):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes of the same launch geometry
-    (FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE); bench.py cannot collect counters itself."""
-    for fn in ("r03_pmc_%s.json" % name, "r02_pmc_%s.json" % name):
+def _pmc_traffic(name, samples, device_kernels):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes of the same launch (FETCH_SIZE x2 per the gfx950
+    note + WRITE_SIZE); bench.py cannot collect counters itself.  A file only counts when it was recorded for the SAME
+    device kernels (the symbols this leg just launched), the same launch size and the same build of the kernel sources
+    (`lib_sha16`); anything else gives traffic = null instead of a stale number (ADVICE r2 / VERDICT r3)."""
+    from tricolour_amd import _lib
+    sha = _lib.source_hash()
+    for fn in ("r04_pmc_%s.json" % name,):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
-            if pmc.get("samples_per_launch") == samples:
-                return pmc["hbm_bytes_per_launch"], "profiles/" + fn
         except Exception:
-            pass
+            continue
+        if (pmc.get("samples_per_launch") == samples and sorted(pmc.get("device_kernels", [])) == sorted(device_kernels)
+                and pmc.get("lib_sha16") == sha):
+            return pmc["hbm_bytes_per_launch"], "profiles/" + fn
     return None, None
+
+
+def _kernel_family(sym):
+    return sym.split("<", 1)[0].strip()
 
 
 def roofline_sumthreshold(torch, device, T, F, kw, nwin):
@@ -246,17 +265,24 @@ def roofline_sumthreshold(torch, device, T, F, kw, nwin):
     warr = (C.c_int64 * len(wins))(*[int(w) for w in wins])
     ms = C.c_float(0)
     stream = torch.cuda.current_stream(device).cuda_stream
+    names = {}
     for reps in (2, 8):
+        _lib.kernel_log_begin()
         _lib.check(lib.tri_bench_sumthreshold(data.data_ptr(), mad.data_ptr(), out.data_ptr(),
                                               nwin, T, F, warr, len(wins),
                                               float(kw.get("outlier_nsigma", 4.5)),
                                               float(kw.get("rho", 1.3)),
                                               int(os.environ.get("TRI_BENCH_ST_VARIANT", "0")), reps,
                                               C.byref(ms), stream))
+        names = _lib.kernel_log_end()
     samples = nwin * T * F
     achieved = samples * ST_BYTES_PER_SAMPLE / (ms.value * 1e-3) / 1e9
-    traffic, src = _pmc_traffic("sumthreshold", samples)
-    return dict(bound="hbm", kernel="k_colst_mask (fused SumThreshold, all windows in one pass, time axis)",
+    devk = sorted(names)
+    traffic, src = _pmc_traffic("sumthreshold", samples, devk)
+    return dict(bound="hbm", kernel="fused SumThreshold (all windows in one pass), time axis: " + ", ".join(devk),
+                device_kernels=devk, launches_per_measurement=1,
+                timed="the kernel alone through the library's measurement hook tri_bench_sumthreshold, in the step's launch "
+                      "geometry, HIP events on the launch stream (not inside the step)",
                 achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=src,
                 algorithmic_bytes_per_launch=samples * ST_BYTES_PER_SAMPLE,
@@ -285,7 +311,6 @@ def roofline_boxfilter(torch, device, T, F, kw, nwin):
              (1, box_radius(swf), "frequency-axis stage fused with the masked division (k_boxf), last background pass")]
     if nit > 1:
         cases.insert(1, (1, box_radius(nit * swf), "frequency-axis stage fused with the masked division (k_boxqf), first background iteration"))
-    dominant = 1        # the fused frequency-axis stage: the largest share of the step's kernel time
     samples = nwin * T * F
     out = []
     for ci, (stage, rad, what) in enumerate(cases):
@@ -293,22 +318,52 @@ def roofline_boxfilter(torch, device, T, F, kw, nwin):
             continue
         bps = BOX_TIME_BYTES_PER_SAMPLE if stage == 0 else BOX_BYTES_PER_SAMPLE
         src = f4 if stage == 0 else wimg
+        names = {}
         try:
             for reps in (1, 4):
+                _lib.kernel_log_begin()
                 _lib.check(lib.tri_bench_boxfilter(data.data_ptr(), src.data_ptr(), ow.data_ptr(), oo.data_ptr(),
                                                    nwin, T, F, rad, stage, 0, reps, C.byref(ms), stream))
+                names = _lib.kernel_log_end()
         except (NotImplementedError, ValueError) as e:
+            _lib.kernel_log_end()
             out.append(dict(bound="hbm", kernel="box filter %s, r = %d" % (what, rad), error=str(e)))
             continue
         achieved = samples * bps / (ms.value * 1e-3) / 1e9
-        traffic, tsrc = _pmc_traffic("boxfilter_s%d_r%d" % (stage, rad), samples)
-        out.append(dict(bound="hbm", kernel="box filter %s, r = %d" % (what, rad),
+        devk = sorted(names)
+        traffic, tsrc = _pmc_traffic("boxfilter_s%d_r%d" % (stage, rad), samples, devk)
+        out.append(dict(bound="hbm", kernel="box filter %s, r = %d: %s" % (what, rad, ", ".join(devk)),
+                        device_kernels=devk, launches_per_measurement=len(devk),
+                        timed="the stage alone through the library's measurement hook tri_bench_boxfilter (the flagger's own "
+                              "route for that radius), in the step's launch geometry, HIP events on the launch stream",
                         achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=tsrc,
                         algorithmic_bytes_per_launch=samples * bps,
                         bytes_per_sample=bps, samples_per_launch=samples,
-                        ms_per_launch=round(ms.value, 4), dominant=(ci == dominant)))
+                        ms_per_launch=round(ms.value, 4)))
     return out
+
+
+def pick_dominant(kernels, step_launches):
+    """The roofline object is the measured kernel whose FAMILY takes the largest share of the timed step:
+    share = (launches of that family in one step, from the library's kernel log) / (launches per measurement)
+    x (measured ms).  Returns (entry, shares)."""
+    fam_count = {}
+    for sym, n in step_launches.items():
+        fam_count[_kernel_family(sym)] = fam_count.get(_kernel_family(sym), 0) + n
+    best, shares = None, []
+    for e in kernels:
+        if "frac" not in e:
+            continue
+        fams = sorted(set(_kernel_family(k) for k in e.get("device_kernels", [])))
+        launches = sum(fam_count.get(f, 0) for f in fams)
+        est = launches / max(e.get("launches_per_measurement", 1), 1) * e["ms_per_launch"]
+        e["step_family_launches"] = launches
+        e["step_share_ms_estimate"] = round(est, 2)
+        shares.append((est, e))
+        if best is None or est > best[0]:
+            best = (est, e)
+    return (best[1] if best else None), shares
 
 
 # ---------------------------------------------------------------------------------------------
@@ -449,6 +504,72 @@ def scatter_leg(torch, dist, tricolour_amd, device, rank, world, kw, ncorr, T, F
     return res
 
 
+def other_workload_legs(torch, tricolour_amd, flagging, device, kw, pname):
+    """Short legs of the two other single-GPU configurations inside the default run, each with its
+    own parity_check: `chain` = BASELINE configs[3] (1 step of 2 scans x 42 bl), `ska` = configs[4] geometry (4 slabs
+    of 32 bl x 2 corr x 512 x 65536 streamed through pinned buffers + the same slabs device-resident)."""
+    from tricolour_amd.strategies import apply_strategies
+    legs = {}
+    # ---- chain
+    nbl, ncorr, T, F, nscans = 42, 4, 1024, 4096, 2
+    scans = [synth_slab(torch, nbl, ncorr, T, F, device, 4321 + 17 * s) for s in range(nscans)]
+    setup = chain_setup(nbl, F)
+    strategies = chain_strategies(kw)
+
+    def step():
+        out = None
+        for v, f in scans:
+            out = apply_strategies(strategies, f, v, **setup)
+        return out
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nvis = nscans * nbl * ncorr * T * F
+    leg = dict(value=round(nvis / dt / 1e6, 2), unit="Mvis/s", ms_per_step=round(dt * 1e3, 3), steps=1, warmup=1,
+               workload="multi-scan chain (BASELINE configs[3]): %d scans x (%d bl x %d corr x %d x %d), each flag_nans_zeros -> "
+                        "apply_static_mask(or) -> flag_autos -> uvcontsub_flagger -> sum_threshold (kwargs=%s), device-resident"
+                        % (nscans, nbl, ncorr, T, F, pname),
+               flagged_fraction=round(float(out.float().mean().item()), 4))
+    del scans, out
+    flagging.release_workspace()
+    torch.cuda.empty_cache()
+    cb, hv, hf, hexp = cpu_baseline(kw, T, F, chain=UVCONTSUB_KW, fixed_windows=16)
+    leg["cpu_baseline"] = cb
+    leg["parity_check"] = parity_check(torch, tricolour_amd, device, kw, hv, hf, hexp, chain=UVCONTSUB_KW)
+    del hv, hf, hexp
+    flagging.release_workspace()
+    torch.cuda.empty_cache()
+    legs["chain"] = leg
+    # ---- ska
+    nbl, ncorr, T, F, slabs = 32, 2, 512, 65536, 4
+    t_stream, t_res, flagged = ska_stream(torch, tricolour_amd, device, kw, nbl, ncorr, T, F, slabs, 1)
+    nvis = nbl * ncorr * T * F * slabs
+    leg = dict(value=round(nvis / t_res / 1e6, 2), unit="Mvis/s", ms_per_step=round(t_res / slabs * 1e3, 3), steps=slabs, warmup=1,
+               workload="SKA-Mid window geometry (BASELINE configs[4], the 1-GPU half): slabs of %d bl x %d corr x %d x %d, "
+                        "sum_threshold_flagger kwargs=%s; value = device-resident rate" % (nbl, ncorr, T, F, pname),
+               pcie_inclusive=dict(value=round(nvis / t_stream / 1e6, 2), unit="Mvis/s", seconds=round(t_stream, 3),
+                                   what="same slabs streamed host->device->host through two pinned buffers on three streams"),
+               flagged_fraction=round(flagged, 4))
+    flagging.release_workspace()
+    torch.cuda.empty_cache()
+    # one 512 x 65536 window at the full parameter set costs the oracle a minute per core: the parity sample of this
+    # short leg takes ONE major iteration (all five background radii); the -m gpu suite holds the two-iteration case
+    pkw = dict(kw, num_major_iterations=1)
+    cb, hv, hf, hexp = cpu_baseline(pkw, T, F, fixed_windows=8)
+    cb["sample"] += "; num_major_iterations=1 for this sample"
+    leg["cpu_baseline"] = cb
+    leg["parity_check"] = parity_check(torch, tricolour_amd, device, pkw, hv, hf, hexp)
+    leg["parity_check"]["kwargs"] = "%s with num_major_iterations=1" % pname
+    del hv, hf, hexp
+    flagging.release_workspace()
+    torch.cuda.empty_cache()
+    legs["ska"] = leg
+    return legs
+
+
 def self_launch(args):
     """`bench.py --gpus N` outside a torchrun environment: start the N ranks as child processes (before any
     GPU call in this process) and relay rank 0's line."""
@@ -492,6 +613,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true")
     ap.add_argument("--no-other-params", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip the short chain / ska legs of the default (slab, N = 1) run")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the per-kernel roofline legs (what the rocprofv3 --pmc passes of profiles/ wrap)")
     ap.add_argument("--dry-run", action="store_true",
@@ -574,7 +697,7 @@ def main():
     if args.roofline_only:
         nwin = min(nbl * ncorr, 1008 if wl != "ska" else 64)
         print(json.dumps({"roofline_kernels": [roofline_sumthreshold(torch, device, T, F, kw, nwin)] +
-                          roofline_boxfilter(torch, device, T, F, kw, nwin)}))
+                          roofline_boxfilter(torch, device, T, F, kw, nwin), "lib_sha16": _lib.source_hash()}))
         return
 
     extra = {}
@@ -618,8 +741,13 @@ def main():
                                             "H2D / kernels / D2H overlapped on three streams (10 B/vis over PCIe)",
                                        seconds=round(t_stream, 3))
     else:
-        for _ in range(warmup):
+        step_launches = {}
+        for w in range(warmup):
+            if rank == 0 and w == warmup - 1:
+                _lib.kernel_log_begin()            # untimed: which kernels one step launches, and how often
             out = step()
+            if rank == 0 and w == warmup - 1:
+                step_launches = _lib.kernel_log_end()
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -690,11 +818,19 @@ def main():
             # stage that runs at the most radii of the parameter set (the fused frequency-axis stage at its
             # largest radius when there are several background iterations, else the time-axis stage);
             # every measured kernel, the SumThreshold kernel among them, is under "roofline_kernels"
-            timed = [k for k in kernels if "frac" in k]
-            dom = [k for k in timed if k.get("dominant")] or timed[1:2] or timed
-            if dom:
-                res["roofline"] = {k: v for k, v in dom[0].items() if k != "dominant"}
-            res["roofline_kernels"] = [{k: v for k, v in e.items() if k != "dominant"} for e in kernels]
+            if wl == "ska" or not step_launches:
+                # (no per-step log on this path: count the launches of one untimed call)
+                pv, pf = synth_slab(torch, min(nbl, 2), ncorr, T, F, device, 5)
+                _lib.kernel_log_begin()
+                tricolour_amd.sum_threshold_flagger(pv, pf, **kw)
+                step_launches = _lib.kernel_log_end()
+                del pv, pf
+                flagging.release_workspace()
+            dom, _ = pick_dominant(kernels, step_launches)
+            if dom is not None:
+                res["roofline"] = dict(dom)
+            res["roofline_kernels"] = kernels
+            res["lib_sha16"] = _lib.source_hash()
         if world == 1 and not args.no_cpu_baseline:
             chain_kw = UVCONTSUB_KW if wl == "chain" else None
             res["cpu_baseline"], hv, hf, hexp = cpu_baseline(kw, T, F, chain=chain_kw)
@@ -703,6 +839,15 @@ def main():
                 flagging.release_workspace()
             del hv, hf, hexp
         torch.cuda.empty_cache()
+        if wl == "slab" and world == 1 and not args.no_other_workloads and not args.no_cpu_baseline and (ncorr, T, F) == (4, 1024, 4096):
+            try:
+                res["other_workloads"] = other_workload_legs(torch, tricolour_amd, flagging, device, kw, pname)
+            except Exception as e:            # the headline line must survive a failing extra leg -- but not silently
+                res["other_workloads"] = dict(error="%s: %s" % (type(e).__name__, e))
+        checks = [res.get("parity_check")] + [l.get("parity_check") for l in res.get("other_workloads", {}).values() if isinstance(l, dict)]
+        checks = [c for c in checks if c]
+        if checks:
+            res["parity_ok"] = all(c.get("parity_ok", False) for c in checks) and "error" not in res.get("other_workloads", {})
     leg_failed = False
     # N > 1: the scatter -> flag -> gather leg comes last, under a watchdog -- a stuck point-to-point transfer
     # must not take the measured line with it
@@ -729,6 +874,8 @@ def main():
     if rank == 0:
         print(json.dumps(res))
         sys.stdout.flush()
+        if res.get("parity_ok") is False and dist is None:
+            sys.exit(4)                    # a parity failure must not look like a green run; the line is out
     if leg_failed:
         # peers may be stuck in the failed leg's transfers: no further collective; abort the group so they
         # fail fast instead of waiting for the collective timeout, and leave with a non-zero code

@@ -313,6 +313,15 @@ int tri_bench_boxfilter(const float *data, const uint8_t *flags4, float *out_w,
 int tri_boxx_last_stats(uint64_t *passes, uint64_t *sequential);
 
 /*
+ * Measurement hook: per-thread kernel log.  op 0 clears the log and switches it on; op 1 writes
+ * "kernel=launches;kernel=launches;..." (demangled device kernel symbols launched by this thread since op 0)
+ * into buf[cap] and switches the log off; op 2 switches it off.  bench.py names the kernels of its roofline
+ * legs with it and derives the step's dominant kernel family from the launch counts.  Returns the number of
+ * distinct kernels (op 1).  No reference counterpart.
+ */
+int tri_kernel_log(int op, char *buf, int64_t cap);
+
+/*
  * Test hook: tri_sum_threshold_flagger that additionally taps the LAST major
  * iteration's intermediates of window 0 into caller-provided device buffers
  * (Fa = averaged channels, N = ntime * Fa):

@@ -3,7 +3,13 @@
 import collections, csv, glob, sys
 d, pat = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "")
 import os
-f = max(glob.glob(d + "/*/*_counter_collection.csv"), key=os.path.getmtime)
+files = glob.glob(d + "/*/*_counter_collection.csv")
+if not files:
+    sys.exit("pmc_report: no counter CSV under %s (did the profiled run fail? see gpurun_out/pmc_passes.log)" % d)
+f = max(files, key=os.path.getmtime)
+import time
+if time.time() - os.path.getmtime(f) > 3600:
+    sys.exit("pmc_report: %s is older than an hour -- a stale pass, not this run's" % f)
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(set)
 for r in csv.DictReader(open(f)):

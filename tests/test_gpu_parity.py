@@ -875,6 +875,42 @@ def test_ska_shaped_window_vs_oracle(gpu, oracle):
     assert nbad == 0, "%d of %d flags differ" % (nbad, out.size)
 
 
+def test_ska_shaped_window_stage1_kwargs_vs_oracle(gpu, oracle):
+    """The same geometry with the stage-1 parameter set of default.yaml (radii [54, 43] ... [10, 8]) and two major
+    iterations: the routes a 64-window SKA slab takes at every radius -- the eight-wave stage pipeline from r = 8 on
+    (few, long lines), the four-wave spectrum pipeline at r = 43 ... 8 on 65536-channel lines, segment-wise NaN
+    interpolation -- flags and the six last-iteration intermediates bit for bit."""
+    rs = np.random.RandomState(56)
+    shape = (1, 2, 512, 65536)
+    vis = np.empty(shape, np.complex64)
+    vis.real = rs.standard_normal(shape).astype(np.float32)
+    vis.imag = rs.standard_normal(shape).astype(np.float32)
+    vis.real[..., ::1013] += 8.0
+    vis.real[:, :, ::101, :] += 5.0
+    vis.real[0, 1, 100:120, 30000:31000] += 2.5
+    vis.real.reshape(-1)[rs.randint(0, vis.size, 2000)] += 50.0
+    vis.real.reshape(-1)[rs.randint(0, vis.size, 40)] = np.nan
+    flags = np.zeros(shape, np.bool_)
+    flags[..., ::64] = True
+    flags[0, 0, :, 20000:20600] = True              # wider than 4 r = 172 channels: NaN background to interpolate
+    kw = dict(SHIPPED_KWARGS["stage1"], num_major_iterations=2)
+    _compare(gpu, oracle, vis, flags, kw, "ska stage1")
+
+
+def test_spectrum_exact_row_filter_taken_by_a_later_iteration_only(gpu, oracle):
+    """the spectrum background picks the exact row filter (K4x) per iteration.  With 5400 channels and
+    spike_width_freq = 64 the first radius (277: padded line 6508 > the longest LDS line) takes the column filter and the
+    second (221: 6284) takes K4x -- which then needs the row copy of the spectra that only the first iteration used to make."""
+    rs = np.random.RandomState(77)
+    shape = (1, 2, 16, 5400)
+    vis = (rs.standard_normal(shape) + 1j * rs.standard_normal(shape)).astype(np.complex64)
+    vis.real += 5.0 + 3.0 * np.sin(np.arange(shape[3]) / 300.0).astype(np.float32)
+    vis[..., ::131] *= 6
+    flags = rs.uniform(size=shape) < 0.03
+    kw = dict(num_major_iterations=2, spike_width_freq=64.0, background_iterations=5)
+    _compare(gpu, oracle, vis, flags, kw, "late exact rows")
+
+
 def test_flag_dtypes_and_non_contiguous_inputs(gpu, oracle):
     """flags of any integer type (non-zero = flagged, flagging.py:833-835;
     cf. the reference's TestAsbool, tests/test_flagging.py:12-34) and

@@ -58,6 +58,33 @@ class TriParams(C.Structure):
     ]
 
 
+def source_hash():
+    """sha256 (16 hex digits) of the kernel sources and build flags: identifies the build a measurement belongs to
+    (bench.py ties the committed PMC traffic files to it)."""
+    import hashlib
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
+    for f in SOURCES + DEPENDS + [HEADER]:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def kernel_log_begin():
+    lib().tri_kernel_log(0, None, 0)
+
+
+def kernel_log_end():
+    """{kernel symbol: launches} of this thread since kernel_log_begin()."""
+    buf = C.create_string_buffer(1 << 16)
+    lib().tri_kernel_log(1, buf, len(buf))
+    out = {}
+    for item in buf.value.decode().split(";"):
+        if "=" in item:
+            k, v = item.rsplit("=", 1)
+            out[k] = int(v)
+    return out
+
+
 def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
@@ -131,6 +158,7 @@ _SIGNATURES = {
                                       C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(C.c_float), C.c_void_p]),
     "tri_boxx_last_stats": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "tri_kernel_log": (C.c_int, [C.c_int, C.c_char_p, C.c_int64]),
     "tri_test_box_divide": (C.c_int, [C.c_int64, C.POINTER(C.c_uint64), C.c_void_p]),
     "tri_test_median": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                   C.c_int64, C.POINTER(C.c_int64), C.c_int64, C.c_int, C.c_void_p]),

@@ -1270,6 +1270,10 @@ int spectrum_background(const Run& r) {
     hipLaunchKernelGGL(k_copy_u8, dim3((unsigned)cdiv(nS, 256)), dim3(256), 0, r.st, ws.sflags, ws.sbgf, nS);
     LAUNCHCHK();
     double rej = TRI_MAD_NORMAL * r.p->background_reject;  // flagging.py:568
+    // the exact row filter (K4x) is picked PER ITERATION (boxx_pick_l depends on the radius: a large first radius may not fit
+    // its LDS line while a later, smaller one does), so the row copy of the spectra is made by the first iteration that
+    // takes that route, whichever it is (it used to be made by the first iteration only)
+    bool rowD_valid = false;
     for (int ext = pl.nit; ext >= 0; ext--) {
         bool final_pass = ext == 0;
         double sigma = (double)(final_pass ? 1 : ext) * r.p->spike_width_freq;  // flagging.py:554, 576
@@ -1287,8 +1291,9 @@ int spectrum_background(const Run& r) {
             LAUNCHCHK();
             int rc = launch_transpose<float>(r, ws.sw, rowW, Fa, Wn, 0, 0, 1);
             if (!rc) rc = launch_transpose<float>(r, ws.so, rowO, Fa, Wn, 0, 0, 1);
-            if (!rc && ext == pl.nit) rc = launch_transpose<float>(r, ws.sdata, rowD, Fa, Wn, 0, 0, 1);
+            if (!rc && !rowD_valid) rc = launch_transpose<float>(r, ws.sdata, rowD, Fa, Wn, 0, 0, 1);
             if (rc) return rc;
+            rowD_valid = true;
             if (final_pass)
                 rc = launch_boxx<2>(r, xl, rowW, rowO, rowD, nullptr, rowR, rowW, Fa, Wn, Fa, rad, 0, 0, 0, 0, 0, 1, reinterpret_cast<uint8_t*>(ws.rowcnt));
             else
@@ -2165,6 +2170,43 @@ extern "C" int tri_bench_boxfilter(const float* data, const uint8_t* flags4, flo
         (void)hipFree(x_stats);
     }
     return TRI_OK;
+}
+
+// Kernel log of the calling thread: op 0 = clear and switch on, op 1 = write "name=count;name=count;..." (demangled
+// kernel symbols, launches since op 0) into buf and switch off, op 2 = switch off.  Returns the number of distinct kernels.
+#include <cxxabi.h>
+extern "C" int tri_kernel_log(int op, char* buf, int64_t cap) {
+    if (op == 0) {
+        if (g_klog) g_klog->clear();
+        g_klog_on = true;
+        return 0;
+    }
+    g_klog_on = false;
+    if (op != 1) return 0;
+    if (!buf || cap <= 0) return set_err(TRI_EINVAL, "kernel log: no buffer");
+    buf[0] = 0;
+    if (!g_klog) return 0;
+    std::vector<std::pair<std::string, long long>> rows;
+    for (const auto& kv : *g_klog) {
+        const char* m = hipKernelNameRefByPtr(kv.first, nullptr);
+        std::string name = m ? m : "?";
+        int st = 0;
+        char* d = m ? abi::__cxa_demangle(m, nullptr, nullptr, &st) : nullptr;
+        if (d && st == 0) { name = d; }
+        if (d) free(d);
+        const size_t par = name.find('(');                      // drop the argument list and a leading "void "
+        if (par != std::string::npos) name.erase(par);
+        if (name.compare(0, 5, "void ") == 0) name.erase(0, 5);
+        rows.emplace_back(name, kv.second);
+    }
+    std::sort(rows.begin(), rows.end());
+    size_t off = 0;
+    for (const auto& r : rows) {
+        const int n = snprintf(buf + off, (size_t)cap - off, "%s=%lld;", r.first.c_str(), r.second);
+        if (n < 0 || off + (size_t)n >= (size_t)cap) break;
+        off += (size_t)n;
+    }
+    return (int)rows.size();
 }
 
 // Test hook: line passes run / redone sequentially by the last tri_bench_boxfilter(stage 1, variant 4) of this thread

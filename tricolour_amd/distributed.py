@@ -54,6 +54,94 @@ def scatter_windows(vis, flags, shape, src=0, group=None, device=None):
     return torch.view_as_complex(vr), f8.view(torch.bool)
 
 
+def stream_plan(shape, world, root_budget_bytes, itemsize_vis=8):
+    """Rounds of the streamed scatter: (baselines per peer and round, number of rounds).  Two staging buffer sets are in
+    flight on the root (round k is on the links while round k + 1 is staged), so a round may hold budget / 2:
+    q = budget / 2 / world / bytes-per-baseline baselines per peer (at least one)."""
+    nbl = int(shape[0])
+    per_bl = int(np.prod(shape[1:])) * (itemsize_vis + 1)          # visibilities + one flag byte per sample
+    b = shard_bounds(nbl, world)
+    largest = max(b[g + 1] - b[g] for g in range(world)) if world > 0 else 0
+    q = max(1, int(root_budget_bytes // 2 // max(world, 1) // max(per_bl, 1)))
+    rounds = (largest + q - 1) // q if largest > 0 else 0
+    return q, rounds
+
+
+def scatter_windows_streamed(reader, shape, root_budget_bytes, src=0, group=None, device=None, stats=None):
+    """The scatter for window sets LARGER than the root can hold (BASELINE configs[2]: 2016 bl x 4 corr x 1024 x 4096 is
+    304 GB of visibilities + flags against 288 GB of HBM -- and the root's own share of it is 38 GB).  The root never holds
+    the set: ``reader(b0, b1)`` (called on `src` only) returns the host-resident ``(vis, flags)`` of baselines [b0, b1) --
+    numpy arrays or CPU tensors, e.g. views of a memory-mapped / pinned window file, the reference's shard axis
+    (apps/tricolour/app.py:449-451) -- and the root streams them out in rounds: per round and peer a piece of at most
+    ``stream_plan()[0]`` baselines is staged on `device` (host -> device copy; CPU for gloo) and sent point-to-point (RCCL:
+    every peer's piece on its own xGMI link), while the next round is being staged into the second buffer set.  At most
+    `root_budget_bytes` of staging memory are alive on the root at any time (`stats["peak_root_bytes"]` records it).
+    Every rank returns its whole baseline slab on `device`, as ``scatter_windows`` does."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    shape = tuple(int(x) for x in shape)
+    b = shard_bounds(shape[0], world)
+    q, rounds = stream_plan(shape, world, root_budget_bytes)
+    dev = device if device is not None else torch.device("cpu")
+    mine = (b[rank + 1] - b[rank],) + shape[1:]
+    vr = torch.empty(mine + (2,), dtype=torch.float32, device=dev)
+    f8 = torch.empty(mine, dtype=torch.uint8, device=dev)
+    if stats is not None:
+        stats.update(rounds=rounds, baselines_per_round_and_peer=q, peak_root_bytes=0)
+
+    def piece(peer, k):
+        lo = min(b[peer] + k * q, b[peer + 1])
+        return lo, min(lo + q, b[peer + 1])
+
+    if rank == src:
+        inflight = []                      # per round: (requests, staged tensors) -- two rounds alive at most
+        for k in range(rounds):
+            if len(inflight) == 2:         # the buffers of round k - 2 are reused now: its sends must be done
+                for r in inflight[0][0]:
+                    r.wait()
+                inflight.pop(0)
+            ops, staged = [], []
+            for peer in range(world):
+                lo, hi = piece(peer, k)
+                if hi <= lo:
+                    continue
+                v, f = reader(lo, hi)
+                v = torch.as_tensor(v)
+                f = torch.as_tensor(f)
+                v = torch.view_as_real(v) if v.is_complex() else v
+                f = f.view(torch.uint8) if f.dtype == torch.bool else f
+                if peer == src:            # the root's own piece goes straight into its slab
+                    vr[lo - b[src]:hi - b[src]].copy_(v, non_blocking=True)
+                    f8[lo - b[src]:hi - b[src]].copy_(f, non_blocking=True)
+                    continue
+                sv = v.contiguous().to(dev, non_blocking=True)
+                sf = f.contiguous().to(dev, non_blocking=True)
+                staged += [sv, sf]
+                ops.append(dist.P2POp(dist.isend, sv, peer, group))
+                ops.append(dist.P2POp(dist.isend, sf, peer, group))
+            if dev.type == "cuda":
+                torch.cuda.current_stream(dev).synchronize()      # staged pieces have landed before they go on the links
+            reqs = dist.batch_isend_irecv(ops) if ops else []
+            inflight.append((reqs, staged))
+            if stats is not None:
+                alive = sum(t.numel() * t.element_size() for _, st in inflight for t in st)
+                stats["peak_root_bytes"] = max(stats["peak_root_bytes"], alive)
+        for reqs, _ in inflight:
+            for r in reqs:
+                r.wait()
+    else:
+        for k in range(rounds):
+            lo, hi = piece(rank, k)
+            if hi <= lo:
+                continue
+            reqs = dist.batch_isend_irecv([dist.P2POp(dist.irecv, vr[lo - b[rank]:hi - b[rank]], src, group),
+                                           dist.P2POp(dist.irecv, f8[lo - b[rank]:hi - b[rank]], src, group)])
+            for r in reqs:
+                r.wait()
+    return torch.view_as_complex(vr), f8.view(torch.bool)
+
+
 def gather_flags(out_local, shape, dst=0, group=None):
     """Inverse fan-in of the per-rank output flag slabs to `dst`; returns the
     full (bl, corr, time, chan) bool tensor on `dst`, None elsewhere."""

@@ -107,11 +107,16 @@ def _workspace(torch, device, nbytes):
     if t is not None and t.numel() >= nbytes:
         cache.move_to_end(key)
         return t
-    for k in [k for k in cache if k[:2] == key[:2]]:
-        del cache[k]
-    t = None
+    if t is not None:
+        # this stream's workspace must GROW: it was sized against the memory the thread's other workspaces on the
+        # device hold, so those go first (a miss for a new stream leaves them alone -- two pipelined pieces on two
+        # side streams keep one workspace each)
+        for k in [k for k in cache if k[:2] == key[:2]]:
+            del cache[k]
+        t = None
     t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
     cache[key] = t
+    cache.move_to_end(key)
     mine = [k for k in cache if k[:2] == key[:2]]
     for k in mine[:-_WS_CACHE_MAX]:
         del cache[k]
@@ -135,19 +140,24 @@ def set_num_threads(n):
 _declared_threads = None
 
 
-def _workspace_budget(torch, device):
+def _workspace_budget(torch, device, share=1.0):
+    """Bytes a call may take for its workspace.  `share`: fraction of the device's free memory this call may claim
+    (the in-call pipeline runs two pieces on two streams: each budgets half)."""
     env = os.environ.get("TRICOLOUR_AMD_WORKSPACE_GB")
     if env:
-        return int(float(env) * (1 << 30))
+        return int(float(env) * (1 << 30) * share)
     free, total = torch.cuda.mem_get_info(device)
-    # what this thread already holds on the device can be reused or released: it counts as available
-    have = sum(t.numel() for k, t in getattr(_tls, "ws", {}).items() if t is not None and k[:2] == (device.type, device.index))
+    # what this thread already holds FOR THIS STREAM can be reused or released: it counts as available.  The workspaces
+    # of its other streams do not -- they may be in flight, and their blocks return to another stream's pool (ADVICE r3)
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    mine = getattr(_tls, "ws", {}).get(key)
+    have = mine.numel() if mine is not None else 0
     nthreads = _declared_threads or int(os.environ.get("TRICOLOUR_AMD_THREADS", "0") or 0)
     if nthreads > 1:
         # a fixed share of the device -- but never more than what is actually free right now (the caller's own
         # slabs, other processes): the batch shrinks instead of the allocation failing
-        return max(min(int(0.6 * total / nthreads), int(0.9 * free) + have), 0)
-    return int(0.6 * (free + have))
+        return max(min(int(0.6 * total / nthreads * share), int(0.9 * free * share) + have), 0)
+    return int(0.6 * (free * share + have))
 
 
 def _pick_batch(lib, p, n_cp, T, F, budget):
@@ -364,7 +374,7 @@ def _flag_numpy_pipelined(torch, lib, p, vis, flags, average_freq):
         st = pair[k & 1]
         st.wait_stream(caller)
         with torch.cuda.stream(st):
-            out, _ = _flag_device(torch, lib, p, vis[b0:b1], flags[b0:b1], average_freq, None)
+            out, _ = _flag_device(torch, lib, p, vis[b0:b1], flags[b0:b1], average_freq, None, share=0.5)
         if pending is not None:
             drain(pending)          # (its kernels were queued before this piece's copy: they ran under it)
         pending = (out, st, b0, b1)
@@ -380,11 +390,12 @@ def _flag_on_current_stream(torch, lib, p, vis, flags, average_freq, _debug):
     return out
 
 
-def _flag_device(torch, lib, p, vis, flags, average_freq, _debug):
+def _flag_device(torch, lib, p, vis, flags, average_freq, _debug, share=1.0):
     """Inputs to the device (if they are not there), the flagger on the current stream; returns the device
     bool tensor and whether the caller handed over numpy arrays."""
     nbl, ncorr, ntime, nchan = (int(s) for s in vis.shape)
     v, f8, code, from_numpy, device = _as_device_inputs(torch, vis, flags)
+    nan_part = None
     if code in (-64, -128):
         # float64 / complex128 input (the reference accepts "real or complex", flagging.py:830-835):
         # its amplitude is np.abs in float64 -- for complex128 numba's hypot(re, im) -- and enters the
@@ -400,8 +411,13 @@ def _flag_device(torch, lib, p, vis, flags, average_freq, _debug):
             # (inf, nan) -> inf like C99 hypot
             amp = torch.hypot(re, im)
             amp = torch.where(torch.isinf(re) | torch.isinf(im), torch.full_like(amp, float("inf")), amp)
-            # a NaN part always flags the sample in the end (flagging.py:777-781), also next to an infinite one
-            amp = torch.where(torch.isnan(re) | torch.isnan(im), torch.full_like(amp, float("nan")), amp)
+            # A NaN part always flags the sample in the end (flagging.py:777-781), also next to an infinite one -- but the
+            # AMPLITUDE of (inf, nan) is +inf (np.abs = hypot), and that is what _average_freq accumulates while the sample
+            # is unflagged (flagging.py:856-861).  So the amplitude stays +inf (as on the complex64 route: k_amplitude4
+            # keeps amplitude and NaN bit apart) and the NaN marks are OR-ed into the result below.
+            nan_part = torch.isnan(re) | torch.isnan(im)
+            if not bool((nan_part & torch.isinf(amp)).any()):
+                nan_part = None                       # every NaN part already shows as a NaN amplitude
         else:
             amp = v.abs()
         if wide:
@@ -412,7 +428,7 @@ def _flag_device(torch, lib, p, vis, flags, average_freq, _debug):
     with torch.cuda.device(device):
         out = torch.empty((nbl, ncorr, ntime, nchan), dtype=torch.uint8, device=device)
         if n_cp > 0 and ntime > 0 and nchan > 0:
-            budget = _workspace_budget(torch, device)
+            budget = _workspace_budget(torch, device, share)
             _batch, nbytes = _pick_batch(lib, p, n_cp, ntime, nchan, budget)
             ws = _workspace(torch, device, nbytes)
             stream = torch.cuda.current_stream(device).cuda_stream
@@ -441,6 +457,8 @@ def _flag_device(torch, lib, p, vis, flags, average_freq, _debug):
                         time_flags=du[fa:fa + n].reshape(ntime, fa).astype(bool),
                         freq_flags=du[fa + n:].reshape(ntime, fa).astype(bool))
             _lib.check(rc)
+            if nan_part is not None and int(p.num_major_iterations) > 0:
+                out |= nan_part.view(torch.uint8)     # flagging.py:777-781 for (inf, nan) samples of complex128 input
         elif ntime <= 0 or nchan <= 0:
             _lib.check(lib.tri_sum_threshold_flagger(
                 v.data_ptr(), code, f8.data_ptr(), out.data_ptr(), n_cp, ntime, nchan,
