@@ -255,7 +255,11 @@ int tri_version(void);
  * 3 = lane-mask cascade (windows 1,2,4,8, window below 2^31 bytes; what 0
  * selects for those), 4 = stage pipeline across the waves of a workgroup with
  * the prefix rings in LDS (K7p; any list of up to eight windows whose rings
- * fit 160 KB, e.g. 32, 48, 64, 128 -- the flagger's route for such lists).
+ * fit 160 KB, e.g. 32, 48, 64, 128 -- the flagger's route for such lists),
+ * 5 = the lane-mask cascade on COLUMN PANELS [n_col / 64][n_line][64] (what the
+ * flagger's time-axis pass runs, and what 0 selects when n_col % 64 == 0): the
+ * row images are re-laid out before the timed region, the flags taken back to
+ * rows after it.
  */
 int tri_bench_sumthreshold(const float *data, const double *mad, uint8_t *out,
                            int64_t n_win, int64_t n_line, int64_t n_col,

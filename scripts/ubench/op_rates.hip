@@ -59,16 +59,22 @@ template <int OP>
 void run(const char* name) {
     double* d;
     hipMalloc(&d, 4096 * sizeof(double));
-    for (int wpb : {64, 128, 256, 512}) {     // 1, 2, 4, 8 waves per CU-ish block: one block per CU
-        k<OP><<<256, wpb>>>(d, 1.0f, wpb);
+    // one block per CU of 1 ... 16 waves, then (round 4) two 16-wave blocks per CU: 8 waves per SIMD -- what one WAVE gets
+    // shows the issue cost, what a full SIMD gets shows the pipe's throughput (cycles per instruction per SIMD = per wave / waves)
+    for (int cfg = 0; cfg < 6; cfg++) {
+        const int wpb = cfg == 0 ? 64 : cfg == 1 ? 128 : cfg == 2 ? 256 : cfg == 3 ? 512 : 1024;
+        const int grid = cfg == 5 ? 512 : 256;
+        k<OP><<<grid, wpb>>>(d, 1.0f, wpb);
         hipDeviceSynchronize();
-        k<OP><<<256, wpb>>>(d, 1.0f, wpb);
+        k<OP><<<grid, wpb>>>(d, 1.0f, wpb);
         hipDeviceSynchronize();
-        std::vector<double> h(512);
-        hipMemcpy(h.data(), d, 512 * sizeof(double), hipMemcpyDeviceToHost);
+        std::vector<double> h(1024);
+        hipMemcpy(h.data(), d, 1024 * sizeof(double), hipMemcpyDeviceToHost);
         double m = 0;
-        for (int b = 0; b < 256; b++) m += h[2 * b];
-        printf("%-28s block %3d threads (%d wave/SIMD): %.2f cycles per instruction per wave\n", name, wpb, wpb / 256 ? wpb / 256 : 0, m / 256);
+        for (int b = 0; b < grid; b++) m += h[2 * b];
+        const double wps = (double)wpb / 256.0 * (grid / 256);
+        printf("%-28s block %4d threads x %d per CU (%.2f wave/SIMD): %.2f cycles per instruction per wave, %.2f per SIMD\n", name, wpb, grid / 256,
+               wps, m / grid, wps >= 1 ? m / grid / wps : m / grid);
     }
     hipFree(d);
 }

@@ -429,7 +429,7 @@ def _run_st_kernel(data, mad, windows, nsigma, rho, variant):
     return out.cpu().numpy().astype(bool)
 
 
-@pytest.mark.parametrize("shape", [(2, 200, 70), (1, 5, 300), (3, 1024, 130), (1, 17, 64), (2, 33, 257)])
+@pytest.mark.parametrize("shape", [(2, 200, 70), (1, 5, 300), (3, 1024, 130), (1, 17, 64), (2, 33, 257), (2, 300, 192), (1, 1024, 256)])
 def test_fused_sumthreshold_kernel_vs_generic_and_oracle(gpu, oracle, shape):
     """The register cascade (windows 1,2,4,8) against the generic kernel and
     against the oracle's _sum_threshold along axis 0, including lines without
@@ -455,6 +455,9 @@ def test_fused_sumthreshold_kernel_vs_generic_and_oracle(gpu, oracle, shape):
         assert np.array_equal(fused, gen)
         mask = _run_st_kernel(data, mad, windows, 4.5, 1.3, 3)
         assert np.array_equal(mask, gen), "lane-mask cascade"
+        if shape[2] % 64 == 0:
+            panel = _run_st_kernel(data, mad, windows, 4.5, 1.3, 5)
+            assert np.array_equal(panel, gen), "lane-mask cascade on column panels"
 
 
 @pytest.mark.parametrize("shape,windows", [((2, 700, 70), (32, 48, 64, 128)), ((1, 300, 64), (32, 48, 64, 128)),
@@ -1090,7 +1093,7 @@ print("DIFF", bad)
                                   "TRI_NO_PACKED_FLAGS", "TRI_FILTER_MULTIPASS", "TRI_ST_GENERIC", "TRI_ST_REGISTER",
                                   "TRI_FILTER_DIRECT_FT", "TRI_FILTER_NO_REGRING", "TRI_FILTER_NO_REGRING_F", "TRI_MEDIAN_3PASS",
                                   "TRI_NO_FUSED_REJECT", "TRI_NO_FT_SPEC_OR", "TRI_NO_FUSED_BEGIN", "TRI_NO_FUSED_DILATE", "TRI_SPEC_NO_PIPE", "TRI_INTERP_ONE_PASS", "TRI_MEDIAN_NO_PREDICT", "TRI_FILTER_NO_PIPE_T", "TRI_FILTER_NO_PIPE_F", "TRI_ST_NO_PIPE",
-                                  "TRI_FILTER_NO_EXACT", "TRI_BOXX_NTI=256", "TRI_FILTER_NO_TF_REJECT", "TRI_FILTER_PIPE_T_B8=0", "TRI_FILTER_PIPE_F_B8=0", "TRI_NO_FUSED_OR",
+                                  "TRI_FILTER_NO_EXACT", "TRI_BOXX_NTI=256", "TRI_FILTER_NO_TF_REJECT", "TRI_FILTER_PIPE_T_B8=0", "TRI_FILTER_PIPE_F_B8=0", "TRI_NO_FUSED_OR", "TRI_FILTER_NO_BOXW", "TRI_ST_NO_PANEL",
                                   "DEFAULT_ROUTES"])
 def test_alternate_kernel_paths(gpu, knob):
     """Every fallback / A-B path selectable through an environment knob (read once

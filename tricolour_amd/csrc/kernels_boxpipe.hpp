@@ -454,7 +454,23 @@ k_boxq_deep(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFl
 #ifndef BOXQF_LW
 #define BOXQF_LW 64
 #endif
-__host__ __device__ constexpr size_t boxqf_lds_bytes(int B) { return (size_t)(2 * 4 * 4 * B * BOXQF_LW + 2 * 2 * B * BOXQF_LW) * 4; }
+// Round 4 -- WHOLE 64-BYTE ROW PIECES with blocks of 8 (BOXQF_DBL): the stage-in used to take 32 bytes of every line per block
+// and found the other half of the 64-byte sector evicted more often than not (PMC: 13.3 bytes read per sample for 12).  Now every
+// SECOND iteration stages a double block -- one float4 per thread, 64 bytes per line -- into stage-1 FIFOs that hold one block
+// more (four + mirror: 4 KB per workgroup, 76 KB in all: still two workgroups per compute unit).  Even register-block counts only
+// (KS = 16, 32, 48, 64, 80: every radius of the shipped strategies); the others keep the single-block staging.
+#ifndef BOXQF_DBL
+#define BOXQF_DBL 1
+#endif
+#ifndef BOXQF_ABLATE_BARRIER
+#define BOXQF_ABLATE_BARRIER 0
+#endif
+__host__ __device__ constexpr bool boxqf_dbl(int KS, int B) { return BOXQF_DBL && B == 8 && (KS / B) % 2 == 0; }
+// double blocks in flight per thread (2 x that many blocks ahead; 2 x it divides or is divided by the register-block count)
+__host__ __device__ constexpr int boxqf_prefetch2(int nblk) { return nblk == 6 ? 3 : (nblk == 10 || nblk == 2 ? 1 : 2); }
+// floats: stage-1 FIFOs [2 images][NF1 + 1 blocks], stage-2..4 FIFOs [2][3][3 + 1 blocks], output blocks [2][2]
+__host__ __device__ constexpr size_t boxqf_lds_floats(int B, bool dbl) { return (size_t)(2 * ((dbl ? 5 : 4) + 3 * 4) * B * BOXQF_LW + 2 * 2 * B * BOXQF_LW); }
+__host__ __device__ constexpr size_t boxqf_lds_bytes(int B, bool dbl = false) { return boxqf_lds_floats(B, dbl) * 4; }
 #define BOXQF_LDS_BYTES boxqf_lds_bytes(16)
 // B = 8: half the FIFO memory and, for delay lines of up to 80 registers, half the register budget: TWO workgroups
 // (four waves per SIMD) share a compute unit -- twice the barriers per position against twice the latency hiding.
@@ -478,17 +494,25 @@ k_boxqf(const float* __restrict__ srcW, unsigned img_gap, float* __restrict__ ds
     constexpr int PP = B / 4;                                  // positions per thread when staging (4 or 2)
     constexpr int FN = B / 8;                                  // (position, line) pairs per thread when finishing (2 or 1)
     constexpr int NBLK = KS / B;
-    constexpr int P = B == 8 ? boxqf_prefetch8(NBLK) : boxq_prefetch(KS);   // (B = 8: KS = 32, 40, 48, 56, 64, 72, 80, 96 -> 4, 5, 3, 7, 4, 3, BOXQF_P10, 4 blocks ahead: 128 registers)
+    constexpr bool DBL = boxqf_dbl(KS, B);                     // stage a double block every second iteration (whole 64-byte row pieces)
+    constexpr int P2 = boxqf_prefetch2(NBLK);                  // ... double blocks in flight
+    constexpr int P = DBL ? 2 * P2 : (B == 8 ? boxqf_prefetch8(NBLK) : boxq_prefetch(KS));   // (B = 8: KS = 32, 40, 48, 56, 64, 72, 80, 96 -> 4, 5, 3, 7, 4, 3, BOXQF_P10, 4 blocks ahead: 128 registers)
     static_assert(KS % B == 0, "register part: whole blocks");
     static_assert(B == 8 || B == 16, "block length");
     constexpr int U = boxq_lcm(NBLK, P);
+    static_assert(!DBL || U % 2 == 0, "double-block staging: an even number of iterations per trip");
     constexpr unsigned OOB = 0x7ffffff0u;
     extern __shared__ float cf_ring[];
     constexpr int LW = BOXQF_LW;
-    typedef float FifoT[4 * B][LW];                            // one stage's input stream: 3 blocks + mirror of the first
+    // one stage's input stream: NF blocks + a mirror of the first (no block read ever wraps); NF = 3, the stage-1 streams of the
+    // double-block staging 4.  Rows of LW floats: [stage-1 of image 0][of image 1][stages 2..4 of image 0][of image 1][output blocks]
+    constexpr int NF1 = DBL ? 4 : 3;
+    constexpr int F1 = (NF1 + 1) * B * LW, FN3 = 4 * B * LW;
     typedef float OutT[B][LW];
-    FifoT* fifo = reinterpret_cast<FifoT*>(cf_ring);           // [2 images][4 stages]
-    OutT* outb = reinterpret_cast<OutT*>(cf_ring + 2 * 4 * 4 * B * LW);   // [2 images][2 blocks]
+    auto fifo_of = [&](int image, int stage) -> float* {
+        return stage == 0 ? cf_ring + image * F1 : cf_ring + 2 * F1 + (image * 3 + stage - 1) * FN3;
+    };
+    OutT* outb = reinterpret_cast<OutT*>(cf_ring + 2 * F1 + 6 * FN3);   // [2 images][2 blocks]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int img = wave >> 2, st = wave & 3;                  // this wave's image and stage
@@ -497,14 +521,20 @@ k_boxqf(const float* __restrict__ srcW, unsigned img_gap, float* __restrict__ ds
     const int R2 = 2 * r;
     const int d = R2 - KS;                                     // host: 0 <= d < 16
     const int NB = (n + 4 * r + B - 1) / B;
-    for (int k = tid; k < 2 * 4 * 4 * B * LW; k += 512) cf_ring[k] = 0.0f;
+    for (int k = tid; k < 2 * F1 + 6 * FN3; k += 512) cf_ring[k] = 0.0f;
 
     // staging: thread -> image (tid >> 8), line (tid & 255) / 4, positions PP (tid & 3) .. + PP - 1 of a block
     const int s_line = (tid & 255) >> 2, s_q = tid & 3;
     const bool s_lok = c0 + s_line < C;
     const float* s_base = srcW + win * sws_img + (size_t)(img ? img_gap : 0u) + (size_t)(s_lok ? c0 + s_line : 0) * ld;
-    float pre[P][PP];
+    float pre[DBL ? P2 : P][DBL ? 4 : PP];
     auto issue = [&](int blk, int q) {
+        if (DBL) {                                             // double block blk: positions 16 blk + 4 s_q .. + 3
+            const int p = blk * 16 + 4 * s_q;
+            const float4 v = *reinterpret_cast<const float4*>(s_base + (p < n ? p : 0));
+            pre[q][0] = v.x; pre[q][1] = v.y; pre[q][DBL ? 2 : 0] = v.z; pre[q][DBL ? 3 : 0] = v.w;
+            return;
+        }
         const int p = blk * B + PP * s_q;                      // n % 4 == 0: the positions are in or out together
         if (PP == 4) {
             const float4 v = *reinterpret_cast<const float4*>(s_base + (p < n ? p : 0));
@@ -533,7 +563,7 @@ k_boxqf(const float* __restrict__ srcW, unsigned img_gap, float* __restrict__ ds
         }
     };
 #pragma unroll
-    for (int q = 0; q < P; q++) { issue(q, q); issue_data(q - 5, q); }
+    for (int q = 0; q < P; q++) { if (!DBL || q < P2) issue(q, q); issue_data(q - 5, q); }
 
     float R[KS];
 #pragma unroll
@@ -544,7 +574,11 @@ k_boxqf(const float* __restrict__ srcW, unsigned img_gap, float* __restrict__ ds
     // input: sums and delay line stay zero) and past its last (results never stored): no branch around the
     // arithmetic, so it can be scheduled together with the finishing work.  Block j - st - 1 sits in FIFO slot
     // (j - st - 1) mod 3; the delayed window starts d rows earlier.
-    int slot = (3 * 8 - st - 1) % 3, s0 = (3 * B * 8 - (st + 1) * B - d) % (3 * B);
+    const int nf = st == 0 ? NF1 : 3;                          // blocks this wave's input FIFO holds
+    int slot = (nf * 8 - st - 1) % nf, s0 = (nf * B * 8 - (st + 1) * B - d) % (nf * B);
+    int oslot = (3 * 8 - st - 1) % 3;                          // the same block in the NEXT stage's FIFO (always three blocks)
+    float* const fin = fifo_of(img, st);
+    float* const fout = fifo_of(img, st < 3 ? st + 1 : 3);
     const int keep_lo = st == 2 ? R2 : 0;
     const int keep_hi = st == 0 ? n + R2 : 0x7fffffff;
     bool line_nan = false;
@@ -556,10 +590,25 @@ k_boxqf(const float* __restrict__ srcW, unsigned img_gap, float* __restrict__ ds
             const int j = j0 + qq;
             const int q = qq % P;
             const int sb = (qq % NBLK) * B;
-            {                                                  // stage block j (transposed) into this image's stage-1 FIFO
+            if (DBL) {
+                if (qq % 2 == 0) {                             // double block j / 2 (transposed) into this image's stage-1 FIFO: rows lslot B + 4 s_q ..
+                    const int q2 = (qq / 2) % P2;
+                    const int p = j * B + 4 * s_q;
+                    const bool ok = s_lok && p < n;            // beyond the line end / the last line: zero input
+                    float* pf = fifo_of(img, 0) + (size_t)(lslot * B + 4 * s_q) * LW + s_line;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) pf[k * LW] = ok ? pre[q2][k] : 0.0f;
+                    if (lslot == 0 && s_q < 2) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) pf[(NF1 * B + k) * LW] = ok ? pre[q2][k] : 0.0f;
+                    }
+                    lslot = lslot == 0 ? 2 : 0;
+                    issue(j / 2 + P2, q2);                     // (always issued: clamped address)
+                }
+            } else {                                           // stage block j (transposed) into this image's stage-1 FIFO
                 const int p = j * B + PP * s_q;
                 const bool ok = s_lok && p < n;                // beyond the line end / the last line: zero input
-                float* pf = &fifo[img * 4][lslot * B + PP * s_q][s_line];
+                float* pf = fifo_of(img, 0) + (size_t)(lslot * B + PP * s_q) * LW + s_line;
 #pragma unroll
                 for (int k = 0; k < PP; k++) pf[k * LW] = ok ? pre[q][k] : 0.0f;
                 if (lslot == 0) {
@@ -568,12 +617,12 @@ k_boxqf(const float* __restrict__ srcW, unsigned img_gap, float* __restrict__ ds
                 }
                 lslot = lslot == 2 ? 0 : lslot + 1;
             }
-            issue(j + P, q);                                   // (always issued: clamped address)
+            if (!DBL) issue(j + P, q);                         // (always issued: clamped address)
             const int b = j - st - 1;
             {
                 const int t0 = b * B;
-                const float* pi = &fifo[wave][slot * B][lane];
-                const float* pd = &fifo[wave][s0][lane];
+                const float* pi = fin + (size_t)(slot * B) * LW + lane;
+                const float* pd = fin + (size_t)s0 * LW + lane;
                 float xin[B], xdel[B], o[B];
 #pragma unroll
                 for (int u = 0; u < B; u++) { xin[u] = pi[u * LW]; xdel[u] = pd[u * LW]; }
@@ -591,7 +640,7 @@ k_boxqf(const float* __restrict__ srcW, unsigned img_gap, float* __restrict__ ds
                     for (int u = 0; u < B; u++) ob[u * LW] = o[u];
                 } else {
                     const bool whole = t0 >= keep_lo && t0 + B <= keep_hi && b >= 0;
-                    float* po = &fifo[wave + 1][slot * B][lane];
+                    float* po = fout + (size_t)(oslot * B) * LW + lane;
                     if (whole) {
 #pragma unroll
                         for (int u = 0; u < B; u++) po[u * LW] = o[u];
@@ -602,13 +651,14 @@ k_boxqf(const float* __restrict__ srcW, unsigned img_gap, float* __restrict__ ds
                             po[u * LW] = o[u];
                         }
                     }
-                    if (slot == 0) {
+                    if (oslot == 0) {
 #pragma unroll
                         for (int u = 0; u < B; u++) po[(3 * B + u) * LW] = o[u];
                     }
                 }
-                slot = slot == 2 ? 0 : slot + 1;
-                s0 = s0 + B >= 3 * B ? s0 + B - 3 * B : s0 + B;
+                slot = slot == nf - 1 ? 0 : slot + 1;
+                oslot = oslot == 2 ? 0 : oslot + 1;
+                s0 = s0 + B >= nf * B ? s0 + B - nf * B : s0 + B;
             }
             {                                                  // finish block j - 5 (stores always issued)
                 const int bs = j - 5;
@@ -643,7 +693,12 @@ k_boxqf(const float* __restrict__ srcW, unsigned img_gap, float* __restrict__ ds
                 }
             }
             issue_data(j + P - 5, q);                          // data samples of the block finished P iterations from now
+#if BOXQF_ABLATE_BARRIER                 // timing-only build (results are wrong on purpose): what the workgroup barrier costs
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#else
             __syncthreads();
+#endif
         }
     }
     if (MODE == 2 && line_nan) nanflag[win * (size_t)C + c] = 1;

@@ -49,7 +49,10 @@ __global__ void k_abs_c64(const float2* __restrict__ z, float* __restrict__ out,
 // `denom` != 0 (float images only): the stored value is x / denom -- the
 // final division of _box_gaussian_filter1d (flagging.py:419), deferred from
 // the latency-bound sequential filter kernel to this bandwidth-bound copy.
-template <typename T>
+// PANEL: the output [C][R] is written as COLUMN PANELS [R / 64][C][64] -- the 64 columns a wave of a column kernel owns
+// are contiguous, and so are the rows it visits one after the other: its walk becomes one linear stream (host: R % 64 == 0).
+// Element (line c, column r) sits at ((r >> 6) * C + c) * 64 + (r & 63).
+template <typename T, bool PANEL = false>
 __global__ void k_transpose(const T* __restrict__ src, T* __restrict__ dst, int R, int C,
                             size_t src_ws, size_t dst_ws, float denom) {
     __shared__ T tile[64][65];
@@ -67,9 +70,34 @@ __global__ void k_transpose(const T* __restrict__ src, T* __restrict__ dst, int 
         if (r < R && c < C) {
             T v = tile[tx][j];
             if (sizeof(T) == 4 && denom != 0.0f) v = (T)((float)v / denom);
-            d[(size_t)c * R + r] = v;
+            if (PANEL) d[((size_t)blockIdx.y * C + c) * 64 + tx] = v;
+            else d[(size_t)c * R + r] = v;
         }
     }
+}
+
+// rows [L][C] -> panel image [C / 64][L][64] (measurement hook only: the flagger's panels come out of k_transpose<T, true>)
+template <typename T>
+__global__ void k_panelize(const T* __restrict__ src, T* __restrict__ dst, int L, int C, size_t ws) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)L * C) return;
+    const int l = (int)(i / C), c = (int)(i % C);
+    dst[blockIdx.y * ws + ((size_t)(c >> 6) * L + l) * 64 + (c & 63)] = src[blockIdx.y * ws + i];
+}
+template <typename T>
+__global__ void k_unpanel_w(const T* __restrict__ src, T* __restrict__ dst, int L, int C, size_t ws) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)L * C) return;
+    const int l = (int)(i / C), c = (int)(i % C);
+    dst[blockIdx.y * ws + i] = src[blockIdx.y * ws + ((size_t)(c >> 6) * L + l) * 64 + (c & 63)];
+}
+// panel image [C / 64][L][64] -> rows [L][C] (debug taps of the panel-layout SumThreshold images)
+template <typename T>
+__global__ void k_unpanel(const T* __restrict__ src, T* __restrict__ dst, int L, int C) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)L * C) return;
+    const int l = (int)(i / C), c = (int)(i % C);
+    dst[i] = src[((size_t)(c >> 6) * L + l) * 64 + (c & 63)];
 }
 
 // uint8 transpose with 4-byte accesses on both sides (R % 4 == 0, C % 4 == 0):
@@ -663,6 +691,9 @@ __global__ void k_combine16(const uint8_t* __restrict__ spec_rows, const uint8_t
 // intermediate image: the two bytes a 16-channel group needs from its
 // neighbours come from the adjacent lanes (or, at wave edges, from memory).
 // grid (ceil(F16/64), T, W), block 64
+// TPANEL: the time-axis SumThreshold flags arrive as column panels [F / 64][T][64] (see k_transpose<T, true>): a 16-channel
+// group is still 16 contiguous bytes, at ((f16 >> 2) * T + t) * 4 + (f16 & 3) in 16-byte units.
+template <bool TPANEL>
 __global__ __launch_bounds__(64) void k_combine_dilate16(const uint8_t* __restrict__ spec_rows, const uint8_t* __restrict__ tflags,
                                                         const uint8_t* __restrict__ fflags, uint8_t* __restrict__ dil,
                                                         int* __restrict__ rowcnt, int T, int F16, int lo, int hi) {
@@ -680,7 +711,8 @@ __global__ __launch_bounds__(64) void k_combine_dilate16(const uint8_t* __restri
         const uint4* fp = reinterpret_cast<const uint4*>(fflags) + base;
         for (int tt = t0; tt < t1; tt++) {
             size_t a = (size_t)tt * F16 + f16;
-            c = or4(c, or4(tp[a], fp[a]));
+            size_t at = TPANEL ? ((size_t)(f16 >> 2) * T + tt) * 4 + (f16 & 3) : a;
+            c = or4(c, or4(tp[at], fp[a]));
         }
     }
     auto edge = [&](int g, int b) -> unsigned {   // combined byte b of group g
@@ -688,7 +720,8 @@ __global__ __launch_bounds__(64) void k_combine_dilate16(const uint8_t* __restri
         unsigned v = spec_rows[(win * (size_t)F16 + g) * 16 + b];
         for (int tt = t0; tt < t1; tt++) {
             size_t a = (base + (size_t)tt * F16 + g) * 16 + b;
-            v |= (unsigned)tflags[a] | (unsigned)fflags[a];
+            size_t at = TPANEL ? (base + ((size_t)(g >> 2) * T + tt) * 4 + (g & 3)) * 16 + b : a;
+            v |= (unsigned)tflags[at] | (unsigned)fflags[a];
         }
         return v;
     };

@@ -942,7 +942,10 @@ k_median_wave(const float* __restrict__ data, const uint8_t* __restrict__ flags,
               double* __restrict__ med, size_t WSd, size_t WSf, size_t RS, size_t ES,
               const int64_t* __restrict__ seg_start, const int64_t* __restrict__ seg_len,
               int R, int G, const uint8_t* __restrict__ flags2 = nullptr, const uint8_t* __restrict__ colflags = nullptr,
-              size_t WScol = 0) {
+              size_t WScol = 0, int panel_rows = 0) {
+    // panel_rows > 0 (VEC4, ES == 1, RS % 64 == 0): `data` and `flags2` are column panels [RS / 64][panel_rows][64] of the
+    // row image (k_transpose<T, true>; the SumThreshold kernels' layout), `flags` and `colflags` plain rows: an aligned group
+    // of four samples is contiguous in either layout.
     // flags2 (optional): a second flag image of the same layout, OR-ed in on the fly; colflags (optional, ES == 1): one flag
     // per column of the rows (a window's spectrum flags, WScol bytes per window) -- the frequency-axis MAD of
     // flagging.py:967-969 sees flags | time_flags | spec_flags without a pass that writes the union first.
@@ -974,9 +977,17 @@ k_median_wave(const float* __restrict__ data, const uint8_t* __restrict__ flags,
             float4 dv = make_float4(0.f, 0.f, 0.f, 0.f);
             uchar4 fv = make_uchar4(1, 1, 1, 1);
             if (i < len + mis) {
-                dv = *reinterpret_cast<const float4*>(d4 + i);
+                const float* dp = d4 + i;                    // the group in the data image / the second flag image
+                const uint8_t* f2p = f2 ? f2 - mis + i : nullptr;
+                if (panel_rows > 0) {
+                    const int col = (int)seg_start[g] - mis + i;
+                    const size_t pi = ((size_t)(col >> 6) * panel_rows + row) * 64 + (col & 63);
+                    dp = data + win * WSd + pi;
+                    if (f2) f2p = flags2 + win * WSf + pi;
+                }
+                dv = *reinterpret_cast<const float4*>(dp);
                 unsigned fw = *reinterpret_cast<const unsigned*>(f4 + i);
-                if (f2) fw |= *reinterpret_cast<const unsigned*>(f2 - mis + i);
+                if (f2) fw |= *reinterpret_cast<const unsigned*>(f2p);
                 if (cf) fw |= *reinterpret_cast<const unsigned*>(cf - mis + i);
                 fv = make_uchar4((unsigned char)(fw & 0xFFu), (unsigned char)((fw >> 8) & 0xFFu), (unsigned char)((fw >> 16) & 0xFFu), (unsigned char)(fw >> 24));
             }

@@ -572,7 +572,10 @@ k_colst_fused(const float* __restrict__ data, const double* __restrict__ med,
 #ifndef ST_MAXBLK
 #define ST_MAXBLK 256
 #endif
-template <int W0, int W1, int W2, int W3>
+// PANEL (round 4): data and out are column panels [C / 64][L][64] (k_transpose<T, true>) -- the rows a wave visits are
+// contiguous (256 bytes of samples, 64 bytes of flags each), its whole walk one linear stream instead of 256-byte / 64-byte
+// pieces a row pitch apart (profiles/r03_stream_mix.txt: 5.3 against 4.3 TB/s for this byte mix).  Host: C % 64 == 0.
+template <int W0, int W1, int W2, int W3, bool PANEL = false>
 __global__ void __launch_bounds__(ST_MAXBLK, ST_MAXBLK >= 1024 ? 1 : 2)
 k_colst_mask(const float* __restrict__ data, const double* __restrict__ med,
              uint8_t* __restrict__ out, const int64_t* __restrict__ chunk_ends,
@@ -606,12 +609,15 @@ k_colst_mask(const float* __restrict__ data, const double* __restrict__ med,
     // Buffer addressing: a wave-uniform descriptor of the padded line block, a
     // constant 32-bit lane offset and a scalar row offset -- no vector
     // address arithmetic.
-    const unsigned rowb = (unsigned)C * 4u;
+    const unsigned rowb = PANEL ? 256u : (unsigned)C * 4u;       // bytes from one row of samples to the next
+    const unsigned orow = PANEL ? 64u : (unsigned)C;             // ... of flags
+    const size_t panel = (size_t)__builtin_amdgcn_readfirstlane(c >> 6);
+    const size_t first = PANEL ? (panel * (size_t)L + (size_t)p0) * 64 : (size_t)p0 * Cs;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(data + win * ws_data + (size_t)p0 * Cs), 0, (int)((unsigned)Lp * rowb), 0x00020000);
+        (void*)(data + win * ws_data + first), 0, (int)((unsigned)Lp * rowb), 0x00020000);
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(out + win * ws_out + (size_t)p0 * Cs), 0, (int)((unsigned)Lp * (unsigned)C), 0x00020000);
-    const int xoff = c * 4, ooff = c;
+        (void*)(out + win * ws_out + first), 0, (int)((unsigned)Lp * orow), 0x00020000);
+    const int xoff = PANEL ? (c & 63) * 4 : c * 4, ooff = PANEL ? (c & 63) : c;
     auto ldo = [&](int soff) {
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xoff, soff, 0));
     };
@@ -731,11 +737,11 @@ k_colst_mask(const float* __restrict__ data, const double* __restrict__ med,
             if (fast) {
                 const bool f = __builtin_amdgcn_inverse_ballot_w64(fA[fs]);
                 __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(f ? 1 : 0), ors, ooff, oso, 0);
-                oso += C;
+                oso += (int)orow;
                 asm("" : "+s"(oso));
             } else if (ef >= o0 && ef < o1) {
                 const bool f = __builtin_amdgcn_inverse_ballot_w64(fA[fs]);
-                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(f ? 1 : 0), ors, ooff, (int)((unsigned)ef * (unsigned)C), 0);
+                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(f ? 1 : 0), ors, ooff, (int)((unsigned)ef * orow), 0);
             }
             fA[fs] = 0;
             // keep every tick's store (and the scalar chains) in its own scheduling region
@@ -754,7 +760,7 @@ k_colst_mask(const float* __restrict__ data, const double* __restrict__ med,
     int nfast = 0;
     for (int b = base; b < nticks && is_fast(b); b += UN) nfast++;
     xso = (int)((unsigned)(base + UN) * rowb);
-    oso = (int)((unsigned)(base - DOUT) * (unsigned)C);
+    oso = (int)((unsigned)(base - DOUT) * orow);
     for (int b = 0; b < nfast; b++) block(std::true_type{}, 0);   // interior blocks do not use base
     base += nfast * UN;
     for (; base < nticks; base += UN) block(std::false_type{}, base);

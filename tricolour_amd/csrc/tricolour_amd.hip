@@ -5,6 +5,7 @@
 //   kernels_median.hpp        K3  exact medians
 //   kernels_boxfilter.hpp     K4  box-Gaussian filter (four forms)
 //   kernels_boxline.hpp / kernels_boxpipe.hpp   K4r register delay lines, K4p / K4q / K4qf stage pipelines
+//   kernels_boxweight.hpp     K4w integer weight image of the time-axis stage (bit / byte / halfword-packed delay lines)
 //   kernels_boxexact.hpp      K4x exact row filter for any radius (LDS-resident line, checked exactness)
 //   kernels_sumthreshold.hpp  K7  fused SumThreshold
 #include <unordered_set>
@@ -14,6 +15,7 @@
 #include "kernels_boxfilter.hpp"
 #include "kernels_boxline.hpp"
 #include "kernels_boxpipe.hpp"
+#include "kernels_boxweight.hpp"
 #include "kernels_boxexact.hpp"
 #include "kernels_sumthreshold.hpp"
 
@@ -408,8 +410,12 @@ int launch_median(const Run& r, const float* data, const uint8_t* flags, double*
                   const int64_t* seg_len, int R, int G, int64_t W, int64_t max_len, bool vec_ok = false,
                   bool rows_aligned = false, bool segs_aligned = false,
                   unsigned* gcand = nullptr, size_t cand_ws = 0, unsigned cand_cap = 0,
-                  const uint8_t* flags2 = nullptr, const uint8_t* colflags = nullptr, size_t WScol = 0) {
+                  const uint8_t* flags2 = nullptr, const uint8_t* colflags = nullptr, size_t WScol = 0, int panel_rows = 0) {
     if ((int64_t)R * G <= 0 || W <= 0) return TRI_OK;
+    // (data / flags2 as column panels: only the 16-byte wave kernels read them -- see median_takes_panels())
+    if (panel_rows > 0 && !(ES == 1 && RS % 64 == 0 && rows_aligned && max_len + (segs_aligned ? 0 : 3) <= 64 * MW_K &&
+                            WSd % 4 == 0 && WSf % 4 == 0 && ((uintptr_t)data % 16 == 0) && ((uintptr_t)flags % 4 == 0)))
+        return set_err(TRI_EUNSUPPORTED, "panel images need wave-sized segments of 64-column aligned rows");
     // (extra flag sources: the wave kernels only -- see median_takes_extra_flags())
     if ((flags2 || colflags) && (max_len > 64 * MW_K || (colflags && ES != 1) || ((uintptr_t)flags2 % 4 != 0) ||
                                  ((uintptr_t)colflags % 4 != 0) || WScol % 4 != 0))
@@ -422,13 +428,13 @@ int launch_median(const Run& r, const float* data, const uint8_t* flags, double*
     const int64_t slack = segs_aligned ? 0 : 3;   // misaligned segment starts cost up to 3 masked slots
     if (max_len + slack <= 64 * 8 && row4)
         hipLaunchKernelGGL((k_median_wave<8, true>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)W), dim3(256), 0, r.st,
-                           data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G, flags2, colflags, WScol);
+                           data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G, flags2, colflags, WScol, panel_rows);
     else if (max_len <= 64 * 8)
         hipLaunchKernelGGL((k_median_wave<8, false>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)W), dim3(256), 0, r.st,
                            data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G, flags2, colflags, WScol);
     else if (max_len + slack <= 64 * MW_K && row4)
         hipLaunchKernelGGL((k_median_wave<MW_K, true>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)W), dim3(256), 0, r.st,
-                           data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G, flags2, colflags, WScol);
+                           data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G, flags2, colflags, WScol, panel_rows);
     else if (max_len <= 64 * MW_K)
         hipLaunchKernelGGL((k_median_wave<MW_K, false>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)W), dim3(256), 0, r.st,
                            data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G, flags2, colflags, WScol);
@@ -544,6 +550,34 @@ int boxr_pick_ks_f(int rad) {
     return off ? 0 : boxr_pick_ks(rad);
 }
 
+// K4w (kernels_boxweight.hpp): the weight image of the time-axis stage in integer arithmetic, one thread per line, for
+// 20 <= 2r <= 110 -- every radius the register-delay-line kernels (K4r, K4q) serve on that axis.  Returns false when it does
+// not apply; the caller's kernels then filter both images as before.  TRI_FILTER_NO_BOXW=1 switches it off (A/B runs, tests).
+thread_local int g_boxw_override = -1;     // tests / benches: 0 = off
+static bool boxw_usable(int rad, int n, int C) {
+    static const bool off = [] { const char* e = getenv("TRI_FILTER_NO_BOXW"); return e && e[0] == '1'; }();
+    if (g_boxw_override == 0 || (off && g_boxw_override < 0)) return false;
+    return 2 * rad >= 20 && 2 * rad <= 110 && n % 4 == 0 && (uint64_t)n * (uint64_t)C * 4u < (1ull << 31);
+}
+template <int R2>
+int launch_boxw_r2(const Run& r, const uint8_t* srcFlags, float* dstW, int n, int C, float denom, size_t sws, size_t dws, int64_t W) {
+    dim3 grid((unsigned)cdiv(C, 64), (unsigned)W);
+    hipLaunchKernelGGL((k_boxw<R2>), grid, dim3(64), 0, r.st, srcFlags, dstW, n, C, box_reciprocal(denom), sws, dws);
+    LAUNCHCHK();
+    return TRI_OK;
+}
+int launch_boxw(const Run& r, const uint8_t* srcFlags, float* dstW, int n, int C, int rad, float denom, size_t sws, size_t dws, int64_t W) {
+#define BOXW_CASE(R2) case R2: return launch_boxw_r2<R2>(r, srcFlags, dstW, n, C, denom, sws, dws, W);
+#define BOXW_CASE5(A) BOXW_CASE(A) BOXW_CASE(A + 2) BOXW_CASE(A + 4) BOXW_CASE(A + 6) BOXW_CASE(A + 8)
+    switch (2 * rad) {
+        BOXW_CASE5(20) BOXW_CASE5(30) BOXW_CASE5(40) BOXW_CASE5(50) BOXW_CASE5(60) BOXW_CASE5(70) BOXW_CASE5(80) BOXW_CASE5(90) BOXW_CASE5(100)
+        BOXW_CASE(110)
+    }
+#undef BOXW_CASE5
+#undef BOXW_CASE
+    return set_err(TRI_EINVAL, "no integer weight filter for radius %d", rad);
+}
+
 template <int KS>
 int launch_boxt_ks(const Run& r, const float* srcData, const uint8_t* srcFlags, float* dstW, float* dstO,
                    int n, int C, int rad, float denom, size_t sws, size_t dws, int64_t W) {
@@ -557,11 +591,14 @@ int launch_boxt_ks(const Run& r, const float* srcData, const uint8_t* srcFlags, 
     }();
     HIPCHK(attr);
     // one launch per image: a compute unit then runs (mostly) one of the two long loop bodies at a time
+    // (the weight image through the integer kernel K4w where it applies)
+    const bool wk = boxw_usable(rad, n, C);
+    if (wk) { const int rc = launch_boxw(r, srcFlags, dstW, n, C, rad, denom, sws, dws, W); if (rc) return rc; }
     if (d > 0) {
-        hipLaunchKernelGGL((k_boxt<KS, true, 0>), grid, dim3(64), lds, r.st, srcData, srcFlags, dstW, n, C, rad, denom, sws, dws);
+        if (!wk) hipLaunchKernelGGL((k_boxt<KS, true, 0>), grid, dim3(64), lds, r.st, srcData, srcFlags, dstW, n, C, rad, denom, sws, dws);
         hipLaunchKernelGGL((k_boxt<KS, true, 1>), grid, dim3(64), lds, r.st, srcData, srcFlags, dstO, n, C, rad, denom, sws, dws);
     } else {
-        hipLaunchKernelGGL((k_boxt<KS, false, 0>), grid, dim3(64), 0, r.st, srcData, srcFlags, dstW, n, C, rad, denom, sws, dws);
+        if (!wk) hipLaunchKernelGGL((k_boxt<KS, false, 0>), grid, dim3(64), 0, r.st, srcData, srcFlags, dstW, n, C, rad, denom, sws, dws);
         hipLaunchKernelGGL((k_boxt<KS, false, 1>), grid, dim3(64), 0, r.st, srcData, srcFlags, dstO, n, C, rad, denom, sws, dws);
     }
     LAUNCHCHK();
@@ -644,7 +681,8 @@ int launch_boxq_ks(const Run& r, const float* srcData, const uint8_t* srcFlags, 
     HIPCHK(attr);
     dim3 grid((unsigned)cdiv(C, 64), (unsigned)W);
     const BoxDenom dn = box_reciprocal(denom);
-    hipLaunchKernelGGL((k_boxq<KS, 0, B>), grid, dim3(256), boxq_lds_bytes(B), r.st, srcData, srcFlags, dstW, n, C, rad, dn, sws, dws);
+    if (boxw_usable(rad, n, C)) { const int rc = launch_boxw(r, srcFlags, dstW, n, C, rad, denom, sws, dws, W); if (rc) return rc; }
+    else hipLaunchKernelGGL((k_boxq<KS, 0, B>), grid, dim3(256), boxq_lds_bytes(B), r.st, srcData, srcFlags, dstW, n, C, rad, dn, sws, dws);
     hipLaunchKernelGGL((k_boxq<KS, 1, B>), grid, dim3(256), boxq_lds_bytes(B), r.st, srcData, srcFlags, dstO, n, C, rad, dn, sws, dws);
     LAUNCHCHK();
     return TRI_OK;
@@ -676,7 +714,8 @@ int launch_boxq_deep(const Run& r, const float* srcData, const uint8_t* srcFlags
     HIPCHK(attr);
     dim3 grid((unsigned)cdiv(C, 64), (unsigned)W);
     const BoxDenom dn = box_reciprocal(denom);
-    hipLaunchKernelGGL((k_boxq_deep<KS, 0>), grid, dim3(256), boxq_lds_bytes(8, 4), r.st, srcData, srcFlags, dstW, n, C, rad, dn, sws, dws);
+    if (boxw_usable(rad, n, C)) { const int rc = launch_boxw(r, srcFlags, dstW, n, C, rad, denom, sws, dws, W); if (rc) return rc; }
+    else hipLaunchKernelGGL((k_boxq_deep<KS, 0>), grid, dim3(256), boxq_lds_bytes(8, 4), r.st, srcData, srcFlags, dstW, n, C, rad, dn, sws, dws);
     hipLaunchKernelGGL((k_boxq_deep<KS, 1>), grid, dim3(256), boxq_lds_bytes(8, 4), r.st, srcData, srcFlags, dstO, n, C, rad, dn, sws, dws);
     LAUNCHCHK();
     return TRI_OK;
@@ -859,7 +898,7 @@ bool st_use_pipe(const StWin& sw) {
 
 int launch_colst(const Run& r, const StWin& sw, const float* data, const double* med,
                  uint8_t* out, const int64_t* d_chunk_ends, int L, int C, int G, size_t ws_data,
-                 size_t ws_out, int64_t W) {
+                 size_t ws_out, int64_t W, bool panel = false) {
     double thr_scale = r.p->outlier_nsigma * TRI_MAD_NORMAL;  // flagging.py:623
     int blk = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
     if (const char* e = getenv("TRI_ST_BLK")) { int b = atoi(e); if (b >= 64 && b <= ST_MAXBLK && C >= b) blk = b; }
@@ -867,12 +906,18 @@ int launch_colst(const Run& r, const StWin& sw, const float* data, const double*
     if (st_use_fused(sw)) {
         StFusedArgs fa;
         for (int j = 0; j < 4; j++) fa.tf[j] = sw.tf[j];
-        if (st_use_mask(L, C))
+        if (panel && !(st_use_mask(L, C) && C % 64 == 0)) return set_err(TRI_EUNSUPPORTED, "panel images: lane-mask SumThreshold kernel on 64-column panels only");
+        if (panel)
+            hipLaunchKernelGGL((k_colst_mask<1, 2, 4, 8, true>), grid, dim3(blk), 0, r.st, data, med, out,
+                               d_chunk_ends, fa, thr_scale, L, C, G, ws_data, ws_out);
+        else if (st_use_mask(L, C))
             hipLaunchKernelGGL((k_colst_mask<1, 2, 4, 8>), grid, dim3(blk), 0, r.st, data, med, out,
                                d_chunk_ends, fa, thr_scale, L, C, G, ws_data, ws_out);
         else
             hipLaunchKernelGGL((k_colst_fused<1, 2, 4, 8>), grid, dim3(blk), 0, r.st, data, med, out,
                                d_chunk_ends, fa, thr_scale, L, C, G, ws_data, ws_out);
+    } else if (panel) {
+        return set_err(TRI_EUNSUPPORTED, "panel images: windows (1, 2, 4, 8) only");
     } else if (st_use_pipe(sw)) {
         // any list of up to eight windows: one window per wave, lagging twin accumulators (K7p)
         const hipError_t attr = lds_optin(reinterpret_cast<const void*>(&k_colst_pipe),
@@ -907,8 +952,14 @@ int launch_interp(const Run& r, float* a, int L, int C, size_t ws, int64_t W, co
 
 template <typename T>
 int launch_transpose(const Run& r, const T* src, T* dst, int R, int C, size_t sws, size_t dws,
-                     int64_t W, float denom = 0.0f) {
+                     int64_t W, float denom = 0.0f, bool panel = false) {
     dim3 grid((unsigned)cdiv(C, 64), (unsigned)cdiv(R, 64), (unsigned)W);
+    if (panel) {
+        if (R % 64 != 0) return set_err(TRI_EUNSUPPORTED, "panel output needs a multiple of 64 columns");
+        hipLaunchKernelGGL((k_transpose<T, true>), grid, dim3(64, 4), 0, r.st, src, dst, R, C, sws, dws, denom);
+        LAUNCHCHK();
+        return TRI_OK;
+    }
     if (sizeof(T) == 1 && R % 4 == 0 && C % 4 == 0 && sws % 4 == 0 && dws % 4 == 0 &&
         ((uintptr_t)src % 4 == 0) && ((uintptr_t)dst % 4 == 0)) {
         dim3 gridw((unsigned)cdiv(C, 64), (unsigned)cdiv(R, 128), (unsigned)W);
@@ -1076,7 +1127,7 @@ int launch_boxqf_ks(const Run& r, const float* srcW, unsigned gap, float* dstW, 
     HIPCHK(attr);
     const BoxDenom denom = box_reciprocal(box_denominator(rad));
     dim3 grid((unsigned)cdiv(C, 64), (unsigned)W);
-    hipLaunchKernelGGL((k_boxqf<KS, MODE, B>), grid, dim3(512), boxqf_lds_bytes(B), r.st, srcW, gap, dstW, dstO, data, n, C, ld, rad,
+    hipLaunchKernelGGL((k_boxqf<KS, MODE, B>), grid, dim3(512), boxqf_lds_bytes(B, boxqf_dbl(KS, B)), r.st, srcW, gap, dstW, dstO, data, n, C, ld, rad,
                        denom, sws_img, dws, ws_data, nanflag);
     LAUNCHCHK();
     return TRI_OK;
@@ -1642,7 +1693,17 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
     // (and redone by the interpolation pass on repaired lines) into ws.Bw
     float* residFT = ws.Bw;   // window stride wsB
     float* residTF = ws.Aw;   // window stride N (the time-axis scratch is free again)
-    rc = launch_transpose<float>(r, residFT, residTF, Fa, T, wsB, N, W);
+    // Column panels for the time-axis SumThreshold (round 4): the TF residual and the time flags as [Fa / 64][T][64], so the
+    // column kernel's row walk is one linear stream.  Who else touches the two images reads panels too: the frequency-axis MAD
+    // (wave medians over row segments: an aligned group of four channels is contiguous either way) and the fused combine /
+    // dilate pass.  Only on the route where exactly those kernels run (TRI_ST_NO_PANEL=1: plain rows everywhere).
+    static const bool no_panel = [] { const char* e = getenv("TRI_ST_NO_PANEL"); return e && e[0] == '1'; }();
+    static const bool no_fused_or_p = [] { const char* e = getenv("TRI_NO_FUSED_OR"); return e && e[0] == '1'; }();
+    static const bool no_fdil_p = [] { const char* e = getenv("TRI_NO_FUSED_DILATE"); return e && e[0] == '1'; }();
+    const bool panel_t = !no_panel && defer_tf && !no_fused_or_p && !no_fdil_p && Fa % 64 == 0 && Fa == F &&
+                         median_takes_extra_flags(pl.maxchunk + 3) && st_use_fused(pl.swT) && st_use_mask(T, Fa) &&
+                         [&] { int64_t e = p->freq_extend; int64_t h = e >= 0 ? e / 2 : -((-e + 1) / 2); return -h == -1 && -h + e == 2; }();
+    rc = launch_transpose<float>(r, residFT, residTF, Fa, T, wsB, N, W, 0.0f, panel_t);
     if (rc) return rc;
 
     // flagging.py:964  SumThreshold along time.  MAD per channel over time =
@@ -1653,7 +1714,7 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
     }
     rc = launch_median(r, residFT, ws.flagsFT, ws.med, wsB, N, (size_t)T, 1, ws.segT_start, ws.segT_len, Fa, 1, W, pl.T, false, T % 4 == 0, true);
     if (rc) return rc;
-    rc = launch_colst(r, pl.swT, residTF, ws.med, ws.tflTF, ws.d_tends, T, Fa, 1, N, N, W);
+    rc = launch_colst(r, pl.swT, residTF, ws.med, ws.tflTF, ws.d_tends, T, Fa, 1, N, N, W, panel_t);
     if (rc) return rc;
 
     // flagging.py:967-969  flags |= time_flags; SumThreshold along frequency.
@@ -1663,9 +1724,10 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
     static const bool no_fused_or = [] { const char* e = getenv("TRI_NO_FUSED_OR"); return e && e[0] == '1'; }();
     if (defer_tf && !no_fused_or && median_takes_extra_flags(pl.maxchunk) && Fa % 4 == 0) {
         rc = launch_median(r, residTF, ws.flagsTF, ws.med, N, N, (size_t)Fa, 1, ws.segC_start, ws.segC_len, T, G, W, pl.maxchunk, false, Fa % 4 == 0,
-                           false, nullptr, 0, 0, ws.tflTF, ws.srows, (size_t)Fa);
+                           false, nullptr, 0, 0, ws.tflTF, ws.srows, (size_t)Fa, panel_t ? T : 0);
         if (rc) return rc;
     } else {
+        if (panel_t) return set_err(TRI_EUNSUPPORTED, "internal: panel images on a route that reads rows");
         if (defer_tf) {
             hipLaunchKernelGGL(k_or_spec_more16, grid1(N / 16, W), dim3(256), 0, r.st, ws.flagsTF, ws.srows, ws.tflTF, T, Fa / 16);
             LAUNCHCHK();
@@ -1685,8 +1747,14 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
         hipLaunchKernelGGL(k_gather_col_f32, dim3((unsigned)cdiv(Fa, 256)), dim3(256), 0, r.st, ws.sres, r.dbg->f32, Fa, Wn, 0);
         hipLaunchKernelGGL(k_gather_col_u8, dim3((unsigned)cdiv(Fa, 256)), dim3(256), 0, r.st, ws.sout, r.dbg->u8, Fa, Wn, 0);
         LAUNCHCHK();
-        HIPCHK(hipMemcpyAsync(r.dbg->f32 + Fa + N, residTF, N * sizeof(float), hipMemcpyDeviceToDevice, r.st));
-        HIPCHK(hipMemcpyAsync(r.dbg->u8 + Fa, ws.tflTF, N, hipMemcpyDeviceToDevice, r.st));
+        if (panel_t) {
+            hipLaunchKernelGGL(k_unpanel<float>, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, r.st, (const float*)residTF, r.dbg->f32 + Fa + N, T, Fa);
+            hipLaunchKernelGGL(k_unpanel<uint8_t>, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, r.st, (const uint8_t*)ws.tflTF, r.dbg->u8 + Fa, T, Fa);
+            LAUNCHCHK();
+        } else {
+            HIPCHK(hipMemcpyAsync(r.dbg->f32 + Fa + N, residTF, N * sizeof(float), hipMemcpyDeviceToDevice, r.st));
+            HIPCHK(hipMemcpyAsync(r.dbg->u8 + Fa, ws.tflTF, N, hipMemcpyDeviceToDevice, r.st));
+        }
         HIPCHK(hipMemcpyAsync(r.dbg->u8 + Fa + N, ws.fflTF, N, hipMemcpyDeviceToDevice, r.st));
     }
 
@@ -1704,9 +1772,11 @@ int run_iteration(Run& r, const void* vis, uint8_t* iter_flags, uint8_t* out_fla
         if (pl.vec && flo == -1 && fhi == 2 && !no_fuse) {
             // both smearings in one pass, no intermediate image
             dim3 grid((unsigned)cdiv(F / 16, 64), (unsigned)T, (unsigned)W);
-            hipLaunchKernelGGL(k_combine_dilate16, grid, dim3(64), 0, r.st, ws.srows, ws.tflTF, ws.fflTF, ws.dil, ws.rowcnt, T, F / 16, lo, hi);
+            if (panel_t) hipLaunchKernelGGL(k_combine_dilate16<true>, grid, dim3(64), 0, r.st, ws.srows, ws.tflTF, ws.fflTF, ws.dil, ws.rowcnt, T, F / 16, lo, hi);
+            else hipLaunchKernelGGL(k_combine_dilate16<false>, grid, dim3(64), 0, r.st, ws.srows, ws.tflTF, ws.fflTF, ws.dil, ws.rowcnt, T, F / 16, lo, hi);
             hipLaunchKernelGGL(k_colcount, grid1(F / 4, W), dim3(256), 0, r.st, ws.dil, ws.colcnt, T, F / 4);
         } else {
+            if (panel_t) return set_err(TRI_EUNSUPPORTED, "internal: panel images on a route that reads rows");
             if (pl.vec)
                 hipLaunchKernelGGL(k_combine16, grid1(N / 16, W), dim3(256), 0, r.st, ws.srows, ws.tflTF, ws.fflTF, ws.comb, T, Fa / 16, lo, hi);
             else
@@ -2029,7 +2099,20 @@ extern "C" int tri_bench_sumthreshold(const float* data, const double* mad, uint
     if ((variant == 2 || variant == 3) && !can_fuse) return set_err(TRI_EUNSUPPORTED, "register cascade needs windows (1,2,4,8)");
     if (variant == 3 && !((uint64_t)L * (uint64_t)C * 4u < (1ull << 31)))
         return set_err(TRI_EUNSUPPORTED, "lane-mask cascade needs a window below 2^31 bytes");
-    if (variant == 0 && can_fuse) variant = st_use_mask(L, C) ? 3 : 2;
+    // variant 5 (round 4): the lane-mask cascade on COLUMN PANELS, as the flagger's time-axis pass runs it -- the row images
+    // handed in are re-laid out before the timed region and the flags taken back to rows after it
+    static const bool no_panel = [] { const char* e = getenv("TRI_ST_NO_PANEL"); return e && e[0] == '1'; }();
+    if (variant == 5 && !(can_fuse && C % 64 == 0 && (uint64_t)L * (uint64_t)C * 4u < (1ull << 31)))
+        return set_err(TRI_EUNSUPPORTED, "panel SumThreshold: windows (1,2,4,8), a multiple of 64 columns, a window below 2^31 bytes");
+    if (variant == 0 && can_fuse) variant = st_use_mask(L, C) ? ((C % 64 == 0 && !no_panel) ? 5 : 3) : 2;
+    float* pdata = nullptr;
+    uint8_t* pout = nullptr;
+    if (variant == 5) {
+        HIPCHK(hipMalloc(&pdata, (size_t)n_win * ws * sizeof(float)));
+        HIPCHK(hipMalloc(&pout, (size_t)n_win * ws));
+        hipLaunchKernelGGL(k_panelize<float>, dim3((unsigned)cdiv((int64_t)ws, 256), (unsigned)n_win), dim3(256), 0, st, data, pdata, L, C, ws);
+        LAUNCHCHK();
+    }
     if (variant == 4) {
         if (sw.nw > 8 || stp_lds_bytes(sw) > 160 * 1024) return set_err(TRI_EUNSUPPORTED, "stage pipeline: more than eight windows, or the flag ring does not fit LDS");
         HIPCHK(lds_optin(reinterpret_cast<const void*>(&k_colst_pipe), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -2039,7 +2122,9 @@ extern "C" int tri_bench_sumthreshold(const float* data, const double* mad, uint
     for (int j = 0; j < 4; j++) fa.tf[j] = sw.tf[j < sw.nw ? j : 0];
     HIPCHK(hipEventRecord(e0, st));
     for (int i = 0; i < repeats; i++) {
-        if (variant == 3)
+        if (variant == 5)
+            hipLaunchKernelGGL((k_colst_mask<1, 2, 4, 8, true>), grid, dim3(blk), 0, st, (const float*)pdata, mad, pout, d_ends, fa, thr_scale, L, C, 1, ws, ws);
+        else if (variant == 3)
             hipLaunchKernelGGL((k_colst_mask<1, 2, 4, 8>), grid, dim3(blk), 0, st, data, mad, out, d_ends, fa, thr_scale, L, C, 1, ws, ws);
         else if (fused)
             hipLaunchKernelGGL((k_colst_fused<1, 2, 4, 8>), grid, dim3(blk), 0, st, data, mad, out, d_ends, fa, thr_scale, L, C, 1, ws, ws);
@@ -2057,6 +2142,13 @@ extern "C" int tri_bench_sumthreshold(const float* data, const double* mad, uint
     *ms_per_launch = ms / repeats;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    if (variant == 5) {
+        hipLaunchKernelGGL(k_unpanel_w<uint8_t>, dim3((unsigned)cdiv((int64_t)ws, 256), (unsigned)n_win), dim3(256), 0, st, (const uint8_t*)pout, out, L, C, ws);
+        LAUNCHCHK();
+        HIPCHK(hipStreamSynchronize(st));
+        (void)hipFree(pdata);
+        (void)hipFree(pout);
+    }
     (void)hipFree(ring);
     (void)hipFree(acc);
     (void)hipFree(d_ends);
@@ -2084,6 +2176,7 @@ extern "C" int tri_bench_boxfilter(const float* data, const uint8_t* flags4, flo
     HIPCHK(hipEventCreate(&e1));
     const size_t N = (size_t)n_line * n_col;
     g_boxr_override = variant == 0 ? -1 : (variant == 1 ? 0 : 1);
+    g_boxw_override = variant == 0 ? -1 : 0;            // the named variants run BOTH images through their own kernels
     // stage 2: 0 = the flagger's route, 1 = register rings, 2 / 3 = stage pipeline with blocks of 16 / 8
     if (stage == 2) { g_boxr_override = -1; g_boxp_override = variant == 0 ? -1 : (variant == 1 ? 0 : (variant == 2 ? 16 : 8)); }
     // stage 0: 0 = the flagger's route, 1 = LDS delay lines, 2 = register delay lines (K4r), 3 = stage pipeline (K4q)
@@ -2150,6 +2243,7 @@ extern "C" int tri_bench_boxfilter(const float* data, const uint8_t* flags4, flo
     g_boxp_override = -1;
     g_boxq_override = -1;
     g_boxq_b8_override = -1;
+    g_boxw_override = -1;
     if (rc) return rc;
     HIPCHK(hipEventRecord(e1, r.st));
     HIPCHK(hipEventSynchronize(e1));
