@@ -317,6 +317,13 @@ int tri_bench_boxfilter(const float *data, const uint8_t *flags4, float *out_w,
 int tri_boxx_last_stats(uint64_t *passes, uint64_t *sequential);
 
 /*
+ * Test hook: counters of the fused block-median + rejection kernel of the background loop (kernels_reject.hpp)
+ * since the last reset -- out4 = {blocks run, blocks that fell back to the three-pass select before the pass,
+ * after it, at the bracket verification}.  Synchronises the device.  No reference counterpart.
+ */
+int tri_medrej_stats(uint64_t *out4, int reset);
+
+/*
  * Measurement hook: per-thread kernel log.  op 0 clears the log and switches it on; op 1 writes
  * "kernel=launches;kernel=launches;..." (demangled device kernel symbols launched by this thread since op 0)
  * into buf[cap] and switches the log off; op 2 switches it off.  bench.py names the kernels of its roofline

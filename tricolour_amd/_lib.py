@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TRICOLOUR_AMD_LIB") or os.path.join(_HERE, "libtricolour_amd.so")
 SOURCES = [os.path.join(_HERE, "csrc", "tricolour_amd.hip")]   # one translation unit
 DEPENDS = [os.path.join(_HERE, "csrc", f) for f in (
-    "tri_common.hpp", "kernels_elementwise.hpp", "kernels_median.hpp", "kernels_boxfilter.hpp", "kernels_boxline.hpp", "kernels_boxpipe.hpp",
+    "tri_common.hpp", "kernels_elementwise.hpp", "kernels_median.hpp", "kernels_reject.hpp", "kernels_boxfilter.hpp", "kernels_boxline.hpp", "kernels_boxpipe.hpp",
     "kernels_boxweight.hpp", "kernels_boxexact.hpp",
     "kernels_sumthreshold.hpp")]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "tricolour_amd.h")
@@ -159,6 +159,7 @@ _SIGNATURES = {
                                       C.POINTER(C.c_float), C.c_void_p]),
     "tri_boxx_last_stats": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "tri_kernel_log": (C.c_int, [C.c_int, C.c_char_p, C.c_int64]),
+    "tri_medrej_stats": (C.c_int, [C.POINTER(C.c_uint64), C.c_int]),
     "tri_test_box_divide": (C.c_int, [C.c_int64, C.POINTER(C.c_uint64), C.c_void_p]),
     "tri_test_median": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                   C.c_int64, C.POINTER(C.c_int64), C.c_int64, C.c_int, C.c_void_p]),

@@ -3,6 +3,7 @@
 //   tri_common.hpp            overview, error plumbing, device helpers
 //   kernels_elementwise.hpp   K1, K2, K5, K6, K8, pack / unpack, strategy steps
 //   kernels_median.hpp        K3  exact medians
+//   kernels_reject.hpp        K3r block median + rejection of the background loop in one pass
 //   kernels_boxfilter.hpp     K4  box-Gaussian filter (four forms)
 //   kernels_boxline.hpp / kernels_boxpipe.hpp   K4r register delay lines, K4p / K4q / K4qf stage pipelines
 //   kernels_boxweight.hpp     K4w integer weight image of the time-axis stage (bit / byte / halfword-packed delay lines)
@@ -12,6 +13,7 @@
 #include "tri_common.hpp"
 #include "kernels_elementwise.hpp"
 #include "kernels_median.hpp"
+#include "kernels_reject.hpp"
 #include "kernels_boxfilter.hpp"
 #include "kernels_boxline.hpp"
 #include "kernels_boxpipe.hpp"
@@ -429,7 +431,7 @@ int launch_median(const Run& r, const float* data, const uint8_t* flags, double*
     if (max_len + slack <= 64 * 8 && row4)
         hipLaunchKernelGGL((k_median_wave<8, true>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)W), dim3(256), 0, r.st,
                            data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G, flags2, colflags, WScol, panel_rows);
-    else if (max_len <= 64 * 8)
+    else if (max_len <= 64 * 8 && panel_rows == 0)               // (panel images: the 16-byte kernels only)
         hipLaunchKernelGGL((k_median_wave<8, false>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)W), dim3(256), 0, r.st,
                            data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G, flags2, colflags, WScol);
     else if (max_len + slack <= 64 * MW_K && row4)
@@ -1415,6 +1417,15 @@ int background2d(const Run& r, bool flagsFT_current) {
     }
     double rej = TRI_MAD_NORMAL * r.p->background_reject;
     bool bgf_ft_stale = false;           // the FT flag bytes lag behind the TF4 words (rows-only rejection iterations)
+    // K3r (round 4): block median + rejection in ONE pass over |data - background| (kernels_reject.hpp).  It writes the updated FT
+    // flags to a SECOND image (its fallback redoes a block from the input flags), so the FT flag image alternates between
+    // ws.bgfFT and ws.fflFT (free until the frequency-axis SumThreshold writes it).  TRI_FUSED_MEDREJ=1 switches it on.
+    // (opt-in for now, TRI_FUSED_MEDREJ=1: one workgroup per block does not stream fast enough -- 3.7 against 3.0 ms per 252
+    //  windows for the two kernels, scripts/ubench/medrej_dev.hip)
+    static const bool no_medrej = [] { const char* e = getenv("TRI_FUSED_MEDREJ"); return !(e && e[0] == '1'); }();
+    static const int medrej_fallback = [] { const char* e = getenv("TRI_MEDREJ_FORCE_FALLBACK"); return e ? atoi(e) : 0; }();
+    uint8_t* cur_ft = ws.bgfFT;
+    uint8_t* alt_ft = ws.fflFT;
     for (int ext = pl.nit; ext >= 0; ext--) {
         bool final_pass = ext == 0;
         double e = (double)(final_pass ? 1 : ext);
@@ -1440,7 +1451,7 @@ int background2d(const Run& r, bool flagsFT_current) {
         const bool time_from_tf4 = r0 > 0 && packed && colfilter_lds_block(r0, Fa) > 0;
         if (bgf_ft_stale && (!time_from_tf4 || (!final_pass && !tf_native))) {
             // an iteration that reads the FT flag bytes follows rows-only ones: they are the 32-bit transpose of the TF4 words
-            rc = launch_transpose<float>(r, reinterpret_cast<const float*>(ws.bgfTF), reinterpret_cast<float*>(ws.bgfFT), T / 4, Fa, N / 4, N / 4, W);
+            rc = launch_transpose<float>(r, reinterpret_cast<const float*>(ws.bgfTF), reinterpret_cast<float*>(cur_ft), T / 4, Fa, N / 4, N / 4, W);
             if (rc) return rc;
             bgf_ft_stale = false;
         }
@@ -1475,7 +1486,7 @@ int background2d(const Run& r, bool flagsFT_current) {
         } else if (r0 > 0) {
             const uint8_t* fl = ws.bgfTF;
             if (packed) {   // byte image needed: rebuild it next to the packed one
-                rc = launch_transpose<uint8_t>(r, ws.bgfFT, ws.comb, Fa, T, N, N, W);
+                rc = launch_transpose<uint8_t>(r, cur_ft, ws.comb, Fa, T, N, N, W);
                 if (rc) return rc;
                 fl = ws.comb;
             }
@@ -1484,7 +1495,7 @@ int background2d(const Run& r, bool flagsFT_current) {
         } else {
             const uint8_t* fl = ws.bgfTF;
             if (packed) {
-                rc = launch_transpose<uint8_t>(r, ws.bgfFT, ws.comb, Fa, T, N, N, W);
+                rc = launch_transpose<uint8_t>(r, cur_ft, ws.comb, Fa, T, N, N, W);
                 if (rc) return rc;
                 fl = ws.comb;
             }
@@ -1568,29 +1579,44 @@ int background2d(const Run& r, bool flagsFT_current) {
                 rc = launch_masked_div<1>(r, ws.Bw, ws.Bo, ws.dataFT, N, wsB, N, W, den_f);
                 if (rc) return rc;
             }
+            static const bool no_fuse = [] { const char* e = getenv("TRI_NO_FUSED_REJECT"); return e && e[0] == '1'; }();
+            {
+                // one pass: median + rejection + TF4 re-pack (K3r).  Scratch per (window, chunk) block: the dead time-stage
+                // images, half for the window's keys, half for the undecided samples' indices
+                const size_t per_block = (wsA / (size_t)G) & ~(size_t)7;
+                const unsigned capq = (unsigned)std::min<size_t>(per_block / 2, 0x3ffffffcu);
+                if (r.pl.vec && wsB % 4 == 0 && wsA % 4 == 0 && packed && !no_fuse && !no_medrej && capq >= 1024 && G <= 65535 &&
+                    (uint64_t)N * 4u < (1ull << 32)) {
+                    hipLaunchKernelGGL(k_median_reject, dim3((unsigned)G, (unsigned)W), dim3(256), 0, r.st, (const float*)ws.Bo, (const uint8_t*)cur_ft,
+                                       alt_ft, ws.bgfTF, ws.med, ws.d_chunk_ends, rej, Fa, T / 4, G, wsB, N,
+                                       reinterpret_cast<unsigned*>(ws.Aw), wsA, capq, capq, medrej_fallback);
+                    LAUNCHCHK();
+                    std::swap(cur_ft, alt_ft);
+                    continue;
+                }
+            }
             // block medians over (all times) x (chunk channels): contiguous in FT
             // (the time stage's images in ws.Aw / ws.Ao are dead here: candidate scratch, wsA / G keys per block)
-            rc = launch_median(r, ws.Bo, ws.bgfFT, ws.med, wsB, N, 0, 1, ws.segB_start, ws.segB_len, 1, G, W, pl.maxchunk * pl.T,
+            rc = launch_median(r, ws.Bo, cur_ft, ws.med, wsB, N, 0, 1, ws.segB_start, ws.segB_len, 1, G, W, pl.maxchunk * pl.T,
                                T % 4 == 0 && wsB % 4 == 0 && N % 4 == 0, false, false,
                                reinterpret_cast<unsigned*>(ws.Aw), wsA, (unsigned)(std::min<size_t>(wsA / (size_t)G, 0x7fffffffu) & ~(size_t)3));
             if (rc) return rc;
-            static const bool no_fuse = [] { const char* e = getenv("TRI_NO_FUSED_REJECT"); return e && e[0] == '1'; }();
             if (r.pl.vec && wsB % 4 == 0 && packed && !no_fuse) {
                 // rejection + TF4 re-pack of the flags in one pass
                 hipLaunchKernelGGL(k_reject4_t, dim3((unsigned)cdiv(T / 4, 64), (unsigned)cdiv(Fa, 64), (unsigned)W), dim3(64, 4), 0, r.st,
-                                   ws.Bo, ws.bgfFT, ws.bgfTF, ws.med, ws.d_chunk_of, rej, Fa, T / 4, G, wsB, N);
+                                   ws.Bo, cur_ft, ws.bgfTF, ws.med, ws.d_chunk_of, rej, Fa, T / 4, G, wsB, N);
                 LAUNCHCHK();
                 continue;
             }
             if (r.pl.vec && wsB % 4 == 0)
-                hipLaunchKernelGGL(k_reject4, grid1(N / 4, W), dim3(256), 0, r.st, ws.Bo, ws.bgfFT, ws.med, ws.d_chunk_of, rej, T / 4, G, N / 4, wsB, N);
+                hipLaunchKernelGGL(k_reject4, grid1(N / 4, W), dim3(256), 0, r.st, ws.Bo, cur_ft, ws.med, ws.d_chunk_of, rej, T / 4, G, N / 4, wsB, N);
             else
-                hipLaunchKernelGGL(k_reject<true>, grid1(N, W), dim3(256), 0, r.st, ws.Bo, ws.bgfFT, ws.med, ws.d_chunk_of, rej, Fa, T, G, wsB, N);
+                hipLaunchKernelGGL(k_reject<true>, grid1(N, W), dim3(256), 0, r.st, ws.Bo, cur_ft, ws.med, ws.d_chunk_of, rej, Fa, T, G, wsB, N);
             LAUNCHCHK();
             if (packed)
-                rc = launch_transpose<float>(r, reinterpret_cast<const float*>(ws.bgfFT), reinterpret_cast<float*>(ws.bgfTF), Fa, T / 4, N / 4, N / 4, W);
+                rc = launch_transpose<float>(r, reinterpret_cast<const float*>(cur_ft), reinterpret_cast<float*>(ws.bgfTF), Fa, T / 4, N / 4, N / 4, W);
             else
-                rc = launch_transpose<uint8_t>(r, ws.bgfFT, ws.bgfTF, Fa, T, N, N, W);
+                rc = launch_transpose<uint8_t>(r, cur_ft, ws.bgfTF, Fa, T, N, N, W);
             if (rc) return rc;
         }
     }
@@ -2301,6 +2327,22 @@ extern "C" int tri_kernel_log(int op, char* buf, int64_t cap) {
         off += (size_t)n;
     }
     return (int)rows.size();
+}
+
+// Test hook: statistics of the fused median + rejection kernel (K3r) since the last reset: blocks run, fallbacks before the
+// pass, after it, at the bracket verification.
+extern "C" int tri_medrej_stats(uint64_t* out4, int reset) {
+    unsigned long long h[4] = {0, 0, 0, 0};
+    HIPCHK(hipDeviceSynchronize());
+    if (out4) {
+        HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_medrej_stats), sizeof(h)));
+        for (int k = 0; k < 4; k++) out4[k] = h[k];
+    }
+    if (reset) {
+        unsigned long long z[4] = {0, 0, 0, 0};
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_medrej_stats), z, sizeof(z)));
+    }
+    return TRI_OK;
 }
 
 // Test hook: line passes run / redone sequentially by the last tri_bench_boxfilter(stage 1, variant 4) of this thread
