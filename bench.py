@@ -390,12 +390,19 @@ def chain_strategies(kw):
             dict(task="sum_threshold", kwargs=kw)]
 
 
-def ska_stream(torch, tricolour_amd, device, kw, nbl, ncorr, T, F, slabs, warmup):
-    """Streams `slabs` window slabs (nbl x ncorr windows of T x F each) through two pinned host buffers:
-    stream A copies slab i+1 host->device while stream B flags slab i and stream C copies the flags of slab
-    i-1 back.  Returns (seconds for `slabs` slabs with transfers, seconds for the same slabs device-resident,
-    flagged fraction)."""
+def ska_stream(torch, tricolour_amd, device, kw, nbl, ncorr, T, F, slabs, warmup, kstreams=2):
+    """Streams `slabs` window slabs (nbl x ncorr windows of T x F each) from two pinned host buffers through
+    `kstreams` + 1 device buffer sets: stream A copies slab i + 1 host->device while the kernel streams flag slabs i
+    (and, with two kernel streams, i - 1) and stream C copies finished flags back.  TWO kernel streams (round 4): the
+    1-D spectrum path of these windows is 65536 sequential steps on two workgroups -- 10 % of a slab's time with 254 CUs
+    idle -- so consecutive slabs run as two concurrent calls (each its own workspace) and one slab's spectrum kernels
+    run under the other's 2-D kernels, the way two dask threads would issue them.  Returns (seconds for `slabs` slabs
+    with transfers, seconds for the same slabs device-resident, flagged fraction)."""
+    from tricolour_amd import flagging
     shape = (nbl, ncorr, T, F)
+    NB = kstreams + 1
+    if kstreams > 1:
+        flagging.set_num_threads(kstreams)              # every concurrent call sizes its workspace against 1 / kstreams of the device
     # host side: two pinned (vis, flags, out) buffer sets filled once with synthetic data
     vis_d, flags_d = synth_slab(torch, nbl, ncorr, T, F, device, 4321)
     hv = [torch.empty(shape, dtype=torch.complex64).pin_memory() for _ in range(2)]
@@ -404,83 +411,102 @@ def ska_stream(torch, tricolour_amd, device, kw, nbl, ncorr, T, F, slabs, warmup
     for k in range(2):
         hv[k].copy_(vis_d)
         hf[k].copy_(flags_d)
-    dv = [torch.empty_like(vis_d) for _ in range(2)]
-    df = [torch.empty_like(flags_d) for _ in range(2)]
-    douts = [None, None]
-    s_in, s_k, s_out = torch.cuda.Stream(device), torch.cuda.Stream(device), torch.cuda.Stream(device)
-    ev_in = [torch.cuda.Event() for _ in range(2)]      # slab landed in dv/df[k]
-    ev_k = [torch.cuda.Event() for _ in range(2)]       # kernels of buffer k done (input reusable, output ready)
-    ev_out = [torch.cuda.Event() for _ in range(2)]     # output of buffer k copied back
+    dv = [vis_d] + [torch.empty_like(vis_d) for _ in range(NB - 1)]
+    df = [flags_d] + [torch.empty_like(flags_d) for _ in range(NB - 1)]
+    douts = [None] * NB
+    s_in, s_out = torch.cuda.Stream(device), torch.cuda.Stream(device)
+    s_k = [torch.cuda.Stream(device) for _ in range(kstreams)]
+    ev_in = [torch.cuda.Event() for _ in range(NB)]     # slab landed in dv/df[b]
+    ev_k = [torch.cuda.Event() for _ in range(NB)]      # kernels of buffer b done (input reusable, output ready)
+    ev_out = [torch.cuda.Event() for _ in range(2)]     # host output buffer h copied into
+
+    def h2d(i):
+        b = i % NB
+        with torch.cuda.stream(s_in):
+            if i >= NB:
+                s_in.wait_event(ev_k[b])                # the kernels that read dv[b] (slab i - NB) are done
+            dv[b].copy_(hv[i & 1], non_blocking=True)
+            df[b].copy_(hf[i & 1], non_blocking=True)
+            ev_in[b].record(s_in)
 
     def run(n):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        with torch.cuda.stream(s_in):
-            dv[0].copy_(hv[0], non_blocking=True)
-            df[0].copy_(hf[0], non_blocking=True)
-            ev_in[0].record(s_in)
+        h2d(0)
         for i in range(n):
-            k = i & 1
+            b = i % NB
             if i + 1 < n:
-                with torch.cuda.stream(s_in):
-                    if i >= 1:
-                        s_in.wait_event(ev_k[1 - k])          # kernels that read dv[1-k] are done
-                    dv[1 - k].copy_(hv[1 - k], non_blocking=True)
-                    df[1 - k].copy_(hf[1 - k], non_blocking=True)
-                    ev_in[1 - k].record(s_in)
-            with torch.cuda.stream(s_k):
-                s_k.wait_event(ev_in[k])
-                if i >= 2:
-                    s_k.wait_event(ev_out[k])                  # previous output of this buffer copied back
-                douts[k] = tricolour_amd.sum_threshold_flagger(dv[k], df[k], **kw)
-                douts[k].record_stream(s_out)
-                ev_k[k].record(s_k)
+                h2d(i + 1)
+            ks = s_k[i % kstreams]
+            with torch.cuda.stream(ks):
+                ks.wait_event(ev_in[b])
+                douts[b] = tricolour_amd.sum_threshold_flagger(dv[b], df[b], **kw)
+                douts[b].record_stream(s_out)
+                ev_k[b].record(ks)
             with torch.cuda.stream(s_out):
-                s_out.wait_event(ev_k[k])
-                ho[k].copy_(douts[k], non_blocking=True)
-                ev_out[k].record(s_out)
+                s_out.wait_event(ev_k[b])
+                ho[i & 1].copy_(douts[b], non_blocking=True)     # (s_out is one stream: copies into a host buffer are ordered)
+                ev_out[i & 1].record(s_out)
         torch.cuda.synchronize()
         return time.perf_counter() - t0
 
-    run(max(warmup, 1))
+    run(max(warmup, kstreams))
     t_stream = run(slabs)
-    # device-resident rate over the same number of slabs
+    # device-resident rate over the same number of slabs (same concurrency, no transfers)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out = None
+    outs = [None] * kstreams
     for i in range(slabs):
-        out = tricolour_amd.sum_threshold_flagger(dv[i & 1], df[i & 1], **kw)
+        with torch.cuda.stream(s_k[i % kstreams]):
+            outs[i % kstreams] = tricolour_amd.sum_threshold_flagger(dv[i % NB], df[i % NB], **kw)
     torch.cuda.synchronize()
     t_res = time.perf_counter() - t0
-    return t_stream, t_res, float(out.float().mean().item())
+    flagged = float(outs[0].float().mean().item())
+    if kstreams > 1:
+        flagging.set_num_threads(1)
+    return t_stream, t_res, flagged
 
 
-def scatter_leg(torch, dist, tricolour_amd, device, rank, world, kw, ncorr, T, F, bl_per_rank, backend):
-    """Rank 0 synthesises world x bl_per_rank baselines, fans the slabs out with batched point-to-point
-    sends (RCCL: each peer's slab rides its own xGMI link), every rank flags its slab, the uint8 flags are
-    gathered back.  Separately timed; never part of `value`."""
+def scatter_leg(torch, dist, tricolour_amd, device, rank, world, kw, ncorr, T, F, bl_per_rank, backend, root_budget_gb=2.0):
+    """Rank 0 holds world x bl_per_rank baselines in (pinned) HOST memory -- the full MeerKAT-64 set of configs[2] is 304 GB
+    and cannot sit on one 288 GB GPU -- and streams them out in rounds within `root_budget_gb` of device staging memory
+    (tricolour_amd.distributed.scatter_windows_streamed: batched point-to-point sends, RCCL: each peer's piece on its own
+    xGMI link, the next round staged while one is on the links); every rank flags its slab, the uint8 flags are gathered
+    back.  Separately timed; never part of `value`."""
     from tricolour_amd import distributed as D
     nbl = world * bl_per_rank
     shape = (nbl, ncorr, T, F)
     comm_dev = device if backend == "nccl" else torch.device("cpu")
-    vis = flags = None
+    hv = hf = None
     if rank == 0:
         vis, flags = synth_slab(torch, nbl, ncorr, T, F, device, 99)
-        if backend != "nccl":
-            vis, flags = vis.cpu(), flags.cpu()
+        try:
+            hv = torch.empty(shape, dtype=torch.complex64).pin_memory()
+            hf = torch.empty(shape, dtype=torch.bool).pin_memory()
+        except RuntimeError:
+            hv, hf = torch.empty(shape, dtype=torch.complex64), torch.empty(shape, dtype=torch.bool)
+        hv.copy_(vis)
+        hf.copy_(flags)
+        del vis, flags
+        torch.cuda.empty_cache()
+
+    def reader(b0, b1):
+        return hv[b0:b1], hf[b0:b1]
 
     def sync():
         torch.cuda.synchronize()
         dist.barrier()
 
+    budget = int(root_budget_gb * (1 << 30))
     # untimed pass over one baseline per rank: the point-to-point connections are set up on first use
     wshape = (world, ncorr, T, F)
-    wv, wf = D.scatter_windows(vis[:world] if rank == 0 else None, flags[:world] if rank == 0 else None, wshape, src=0, device=comm_dev)
+    wv, wf = D.scatter_windows_streamed(reader if rank == 0 else None, wshape, budget, src=0, device=comm_dev)
     D.gather_flags(wf.view(torch.uint8), wshape, dst=0)
     del wv, wf
     sync()
+    stats = {}
     t0 = time.perf_counter()
-    v, f = D.scatter_windows(vis, flags, shape, src=0, device=comm_dev)
+    v, f = D.scatter_windows_streamed(reader if rank == 0 else None, shape, budget, src=0, device=comm_dev, stats=stats)
     sync()
     t1 = time.perf_counter()
     out = tricolour_amd.sum_threshold_flagger(v.to(device), f.to(device), **kw)
@@ -497,10 +523,12 @@ def scatter_leg(torch, dist, tricolour_amd, device, rank, world, kw, ncorr, T, F
         sent = (nbl - bl_per_rank) * ncorr * T * F      # samples that left / re-entered the root
         ok = abs(float(full.sum().item()) - float(cnt.item())) < 0.5
         res = dict(backend="rccl" if backend == "nccl" else backend, baselines_per_rank=bl_per_rank,
+                   scatter="streamed from pinned host memory in %d rounds of %d baselines per peer, root staging budget %.1f GiB (peak %.2f GiB)"
+                           % (stats.get("rounds", 0), stats.get("baselines_per_round_and_peer", 0), root_budget_gb, stats.get("peak_root_bytes", 0) / 2**30),
                    scatter_gb_s=round(sent * 9 / (t1 - t0) / 1e9, 2), gather_gb_s=round(sent / (t3 - t2) / 1e9, 2),
                    scatter_s=round(t1 - t0, 4), flag_s=round(t2 - t1, 4), gather_s=round(t3 - t2, 4),
                    flag_count_matches=bool(ok))
-    del vis, flags, v, f, out, full
+    del hv, hf, v, f, out, full
     return res
 
 
@@ -600,6 +628,8 @@ def main():
     ap.add_argument("--time", type=int, default=None)
     ap.add_argument("--chan", type=int, default=None)
     ap.add_argument("--scans", type=int, default=3, help="chain: scans per step")
+    ap.add_argument("--ska-streams", type=int, default=2, choices=[1, 2],
+                    help="ska: concurrent calls (kernel streams); 1 = one slab at a time as in round 3")
     ap.add_argument("--params", choices=sorted(PARAM_SETS), default=None)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
@@ -734,7 +764,7 @@ def main():
     out = None
     if wl == "ska":
         barrier()
-        t_stream, dt, flagged = ska_stream(torch, tricolour_amd, device, kw, nbl, ncorr, T, F, steps, warmup)
+        t_stream, dt, flagged = ska_stream(torch, tricolour_amd, device, kw, nbl, ncorr, T, F, steps, warmup, args.ska_streams)
         barrier()
         extra["pcie_inclusive"] = dict(value=round(nvis_step * steps * world / t_stream / 1e6, 2), unit="Mvis/s",
                                        what="same slabs streamed host->device->host through two pinned buffers, "

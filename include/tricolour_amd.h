@@ -317,11 +317,14 @@ int tri_bench_boxfilter(const float *data, const uint8_t *flags4, float *out_w,
 int tri_boxx_last_stats(uint64_t *passes, uint64_t *sequential);
 
 /*
- * Test hook: counters of the fused block-median + rejection kernel of the background loop (kernels_reject.hpp)
- * since the last reset -- out4 = {blocks run, blocks that fell back to the three-pass select before the pass,
- * after it, at the bracket verification}.  Synchronises the device.  No reference counterpart.
+ * Test hook: counters of the one-pass block-median + rejection kernels of the background loop (kernels_reject.hpp,
+ * kernels_reject_tile.hpp) since the last reset -- out20[0..2] = blocks the one-workgroup form (K3r) ran, fell back
+ * before / after its pass; [3] = second rounds of the tile-parallel form (K3t: median outside the predicted window or
+ * the decision bracket); [4 + r] = blocks K3t handed to the one-workgroup redo for reason r (1 nothing to predict
+ * from, 2 / 10 a wave's window-key / undecided list overflowed, 3 empty, 4 median in an end bin, 5 a block list
+ * overflowed, 6 / 7 window / bracket miss in round 2).  Synchronises the device.  No reference counterpart.
  */
-int tri_medrej_stats(uint64_t *out4, int reset);
+int tri_medrej_stats(uint64_t *out20, int reset);
 
 /*
  * Measurement hook: per-thread kernel log.  op 0 clears the log and switches it on; op 1 writes

@@ -73,9 +73,11 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e3, 0));
         hipLaunchKernelGGL(k_mr_predict, dim3(G, W), dim3(256), 0, 0, resid, fin, ends, scale, T / 4, G, N, N, scratch, wsS, ccap, ucap, 0);
         CK(hipEventRecord(e4, 0));
-        hipLaunchKernelGGL(k_mr_pass, dim3((T / 4 + 63) / 64, ytiles, W), dim3(256), 0, 0, resid, fin, fc, tc, ends, F, T / 4, G, N, N, scratch, wsS, ccap, ucap);
+        hipLaunchKernelGGL(k_mr_pass, dim3((T / 4 + 63) / 64, ytiles, W), dim3(256), 0, 0, resid, fin, fc, tc, ends, F, T / 4, G, N, N, scratch, wsS, ccap, ucap, 1u);
         CK(hipEventRecord(e5, 0));
-        hipLaunchKernelGGL(k_mr_finish, dim3(G, W), dim3(256), 0, 0, fc, tc, mc, scale, F, T / 4, G, N, scratch, wsS, ccap, ucap);
+        hipLaunchKernelGGL(k_mr_finish, dim3(G, W), dim3(256), 0, 0, resid, fin, fc, tc, mc, ends, scale, F, T / 4, G, N, N, scratch, wsS, ccap, ucap, 1u);
+        hipLaunchKernelGGL(k_mr_pass, dim3((T / 4 + 63) / 64, ytiles, W), dim3(256), 0, 0, resid, fin, fc, tc, ends, F, T / 4, G, N, N, scratch, wsS, ccap, ucap, 2u);
+        hipLaunchKernelGGL(k_mr_finish, dim3(G, W), dim3(256), 0, 0, resid, fin, fc, tc, mc, ends, scale, F, T / 4, G, N, N, scratch, wsS, ccap, ucap, 2u);
         CK(hipEventRecord(e6, 0));
         hipLaunchKernelGGL(k_median_reject, dim3(G, W), dim3(256), 0, 0, resid, fin, fc, tc, mc, ends, scale, F, T / 4, G, N, N, scratch, wsS, 0u, 0u, 1,
                            (const unsigned*)scratch, wsS, MRT_PARW, 11);
@@ -84,7 +86,7 @@ int main(int argc, char** argv) {
         float t1, t2, t3, t4, t5, t6;
         CK(hipEventElapsedTime(&t1, e0, e1)); CK(hipEventElapsedTime(&t2, e1, e2));
         CK(hipEventElapsedTime(&t3, e3, e4)); CK(hipEventElapsedTime(&t4, e4, e5)); CK(hipEventElapsedTime(&t5, e5, e6)); CK(hipEventElapsedTime(&t6, e6, e7));
-        if (rep == 1) printf("%d windows of %d x %d, %d chunks: k_median2 + k_reject4_t %.3f ms, k_median_reject %.3f ms, tile form %.3f ms = predict %.3f + pass %.3f (%.2f TB/s at 7 B/sample) + finish %.3f + redo %.3f\n",
+        if (rep == 1) printf("%d windows of %d x %d, %d chunks: k_median2 + k_reject4_t %.3f ms, k_median_reject %.3f ms, tile form %.3f ms = predict %.3f + pass %.3f (%.2f TB/s at 7 B/sample) + finish and round 2 %.3f + redo %.3f\n",
                              W, T, F, G, t1, t2, t3 + t4 + t5 + t6, t3, t4, (double)W * N * 7 / (t4 * 1e-3) / 1e12, t5, t6);
     }
     std::vector<uint8_t> a(W * N), b(W * N);
@@ -105,13 +107,17 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(m2.data(), mc, W * G * 8, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < m1.size(); i++) bm += memcmp(&m1[i], &m2[i], 8) != 0;
         std::vector<unsigned> par((size_t)G * MRT_PARW);
-        size_t redo = 0, nc = 0, nu = 0;
+        size_t redo = 0, nc = 0, nu = 0, brk = 0; int why[16] = {0};
         for (int w = 0; w < W; w++) {
             CK(hipMemcpy(par.data(), scratch + (size_t)w * wsS, par.size() * 4, hipMemcpyDeviceToHost));
-            for (int g = 0; g < G; g++) { redo += par[g * MRT_PARW + 11] == 0; nc += par[g * MRT_PARW + 8]; nu += par[g * MRT_PARW + 9]; }
+            for (int g = 0; g < G; g++) { if (par[g * MRT_PARW + 11] == 0) { why[par[g * MRT_PARW + 13] & 15]++; const unsigned* q = &par[g * MRT_PARW];
+                printf("  redo w %d g %d: lo %08x S %u wlo %u whi %u ncand %u nund %u below1 %08x rounds %u why %u\n", w, g, q[0], q[1], q[2], q[3], q[8], q[9], q[10], q[12], q[13]); } redo += par[g * MRT_PARW + 11] == 0; brk += par[g * MRT_PARW + 12]; nc += par[g * MRT_PARW + 8]; nu += par[g * MRT_PARW + 9]; }
         }
-        printf("tile form: FT flags differing %zu, TF4 %zu, medians %zu; blocks redone %zu of %d, window keys %.2f %%, undecided %.2f %% of the samples\n",
-               bf, bt, bm, redo, W * G, 100.0 * nc / (W * (double)N), 100.0 * nu / (W * (double)N));
+        printf("tile form: FT flags differing %zu, TF4 %zu, medians %zu; blocks redone by one workgroup %zu, second rounds %zu of %d, window keys %.2f %%, undecided %.2f %% of the samples\n",
+               bf, bt, bm, redo, brk, W * G, 100.0 * nc / (W * (double)N), 100.0 * nu / (W * (double)N));
+        printf("redo reasons (1 nothing to predict from, 2 window-key list overflow, 10 undecided list overflow, 3 empty, 4 end bin, 5 global list, 6 window miss in round 2, 7 bracket miss in round 2):");
+        for (int k = 0; k < 16; k++) if (why[k]) printf(" %d:%d", k, why[k]);
+        printf("\n");
         badf += bf; badt += bt; badm += bm;
     }
     unsigned long long st[4];

@@ -1093,7 +1093,7 @@ print("DIFF", bad)
                                   "TRI_NO_PACKED_FLAGS", "TRI_FILTER_MULTIPASS", "TRI_ST_GENERIC", "TRI_ST_REGISTER",
                                   "TRI_FILTER_DIRECT_FT", "TRI_FILTER_NO_REGRING", "TRI_FILTER_NO_REGRING_F", "TRI_MEDIAN_3PASS",
                                   "TRI_NO_FUSED_REJECT", "TRI_NO_FT_SPEC_OR", "TRI_NO_FUSED_BEGIN", "TRI_NO_FUSED_DILATE", "TRI_SPEC_NO_PIPE", "TRI_INTERP_ONE_PASS", "TRI_MEDIAN_NO_PREDICT", "TRI_FILTER_NO_PIPE_T", "TRI_FILTER_NO_PIPE_F", "TRI_ST_NO_PIPE",
-                                  "TRI_FILTER_NO_EXACT", "TRI_BOXX_NTI=256", "TRI_FILTER_NO_TF_REJECT", "TRI_FILTER_PIPE_T_B8=0", "TRI_FILTER_PIPE_F_B8=0", "TRI_NO_FUSED_OR", "TRI_FILTER_NO_BOXW", "TRI_ST_NO_PANEL", "TRI_FUSED_MEDREJ", "TRI_FUSED_MEDREJ=1;TRI_MEDREJ_FORCE_FALLBACK=1",
+                                  "TRI_FILTER_NO_EXACT", "TRI_BOXX_NTI=256", "TRI_FILTER_NO_TF_REJECT", "TRI_FILTER_PIPE_T_B8=0", "TRI_FILTER_PIPE_F_B8=0", "TRI_NO_FUSED_OR", "TRI_FILTER_NO_BOXW", "TRI_ST_NO_PANEL", "TRI_FUSED_MEDREJ", "TRI_FUSED_MEDREJ=1;TRI_MEDREJ_FORCE_FALLBACK=1", "TRI_NO_TILE_MEDREJ", "TRI_MEDREJ_FORCE_FALLBACK",
                                   "DEFAULT_ROUTES"])
 def test_alternate_kernel_paths(gpu, knob):
     """Every fallback / A-B path selectable through an environment knob (read once

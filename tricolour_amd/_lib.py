@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TRICOLOUR_AMD_LIB") or os.path.join(_HERE, "libtricolour_amd.so")
 SOURCES = [os.path.join(_HERE, "csrc", "tricolour_amd.hip")]   # one translation unit
 DEPENDS = [os.path.join(_HERE, "csrc", f) for f in (
-    "tri_common.hpp", "kernels_elementwise.hpp", "kernels_median.hpp", "kernels_reject.hpp", "kernels_boxfilter.hpp", "kernels_boxline.hpp", "kernels_boxpipe.hpp",
+    "tri_common.hpp", "kernels_elementwise.hpp", "kernels_median.hpp", "kernels_reject.hpp", "kernels_reject_tile.hpp", "kernels_boxfilter.hpp", "kernels_boxline.hpp", "kernels_boxpipe.hpp",
     "kernels_boxweight.hpp", "kernels_boxexact.hpp",
     "kernels_sumthreshold.hpp")]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "tricolour_amd.h")

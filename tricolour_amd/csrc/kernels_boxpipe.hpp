@@ -462,6 +462,9 @@ k_boxq_deep(const float* __restrict__ srcData, const uint8_t* __restrict__ srcFl
 #ifndef BOXQF_DBL
 #define BOXQF_DBL 1
 #endif
+#ifndef BOXQF_PAIR
+#define BOXQF_PAIR 1                     // FIFO rows stored in pairs (8-byte LDS accesses) where the register budget allows
+#endif
 #ifndef BOXQF_ABLATE_BARRIER
 #define BOXQF_ABLATE_BARRIER 0
 #endif
@@ -513,6 +516,26 @@ k_boxqf(const float* __restrict__ srcW, unsigned img_gap, float* __restrict__ ds
         return stage == 0 ? cf_ring + image * F1 : cf_ring + 2 * F1 + (image * 3 + stage - 1) * FN3;
     };
     OutT* outb = reinterpret_cast<OutT*>(cf_ring + 2 * F1 + 6 * FN3);   // [2 images][2 blocks]
+    // Round 4 -- FIFO rows are stored in PAIRS: positions 2p and 2p + 1 of a line sit next to each other (element (row, line) at
+    // ((row >> 1) * LW + line) * 2 + (row & 1)), so a stage takes / hands on two positions with one 8-byte LDS access
+    // (ds_read_b64 runs at twice ds_read_b32's bytes per clock, ds_write_b64 at 4/3 of ds_write_b32's; MI355X_MICROARCH.md, LDS) and
+    // the transposing stage-in writes 8 bytes per thread without a bank conflict (it was four-way).  Every row offset a
+    // block starts from is even: blocks of 8 / 16, FIFO delay d = 2r - KS with 2r and KS even.
+    // Only where the registers allow it (KS <= 40 at the 128-register bound of blocks of 8): the 8-byte accesses want aligned
+    // register pairs, and with 48 ... 80 delay registers that spills 23 - 41 dwords (r = 25 ... 43: 17.4 -> 42 ... 53 ms);
+    // at KS = 32 it buys 3 % (16.45 -> 15.99 ms per 1008-window launch).  The other instantiations keep one row per position.
+    constexpr bool PAIR = BOXQF_PAIR && B == 8 && KS <= 40;
+    auto ld2 = [&](const float* fifo, int row) -> float2 {               // rows row, row + 1 (row even) of this lane's line
+        if (PAIR) return *reinterpret_cast<const float2*>(fifo + ((size_t)(row >> 1) * LW + (threadIdx.x & 63)) * 2);
+        const float* p = fifo + (size_t)row * LW + (threadIdx.x & 63);
+        return make_float2(p[0], p[LW]);
+    };
+    auto st2 = [&](float* fifo, int row, int line, float a, float b2) {
+        if (PAIR) { *reinterpret_cast<float2*>(fifo + ((size_t)(row >> 1) * LW + line) * 2) = make_float2(a, b2); return; }
+        float* p = fifo + (size_t)row * LW + line;
+        p[0] = a;
+        p[LW] = b2;
+    };
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int img = wave >> 2, st = wave & 3;                  // this wave's image and stage
@@ -595,12 +618,14 @@ k_boxqf(const float* __restrict__ srcW, unsigned img_gap, float* __restrict__ ds
                     const int q2 = (qq / 2) % P2;
                     const int p = j * B + 4 * s_q;
                     const bool ok = s_lok && p < n;            // beyond the line end / the last line: zero input
-                    float* pf = fifo_of(img, 0) + (size_t)(lslot * B + 4 * s_q) * LW + s_line;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) pf[k * LW] = ok ? pre[q2][k] : 0.0f;
+                    float* pf = fifo_of(img, 0);
+                    const int r0 = lslot * B + 4 * s_q;
+                    const float v0 = ok ? pre[q2][0] : 0.0f, v1 = ok ? pre[q2][1] : 0.0f, v2 = ok ? pre[q2][DBL ? 2 : 0] : 0.0f, v3 = ok ? pre[q2][DBL ? 3 : 0] : 0.0f;
+                    st2(pf, r0, s_line, v0, v1);
+                    st2(pf, r0 + 2, s_line, v2, v3);
                     if (lslot == 0 && s_q < 2) {
-#pragma unroll
-                        for (int k = 0; k < 4; k++) pf[(NF1 * B + k) * LW] = ok ? pre[q2][k] : 0.0f;
+                        st2(pf, NF1 * B + r0, s_line, v0, v1);
+                        st2(pf, NF1 * B + r0 + 2, s_line, v2, v3);
                     }
                     lslot = lslot == 0 ? 2 : 0;
                     issue(j / 2 + P2, q2);                     // (always issued: clamped address)
@@ -608,12 +633,13 @@ k_boxqf(const float* __restrict__ srcW, unsigned img_gap, float* __restrict__ ds
             } else {                                           // stage block j (transposed) into this image's stage-1 FIFO
                 const int p = j * B + PP * s_q;
                 const bool ok = s_lok && p < n;                // beyond the line end / the last line: zero input
-                float* pf = fifo_of(img, 0) + (size_t)(lslot * B + PP * s_q) * LW + s_line;
+                float* pf = fifo_of(img, 0);
+                const int r0 = lslot * B + PP * s_q;
 #pragma unroll
-                for (int k = 0; k < PP; k++) pf[k * LW] = ok ? pre[q][k] : 0.0f;
-                if (lslot == 0) {
-#pragma unroll
-                    for (int k = 0; k < PP; k++) pf[(3 * B + k) * LW] = ok ? pre[q][k] : 0.0f;
+                for (int k = 0; k < PP; k += 2) {
+                    const float va = ok ? pre[DBL ? 0 : q][k] : 0.0f, vb = ok ? pre[DBL ? 0 : q][k + 1] : 0.0f;
+                    st2(pf, r0 + k, s_line, va, vb);
+                    if (lslot == 0) st2(pf, 3 * B + r0 + k, s_line, va, vb);
                 }
                 lslot = lslot == 2 ? 0 : lslot + 1;
             }
@@ -621,11 +647,12 @@ k_boxqf(const float* __restrict__ srcW, unsigned img_gap, float* __restrict__ ds
             const int b = j - st - 1;
             {
                 const int t0 = b * B;
-                const float* pi = fin + (size_t)(slot * B) * LW + lane;
-                const float* pd = fin + (size_t)s0 * LW + lane;
                 float xin[B], xdel[B], o[B];
 #pragma unroll
-                for (int u = 0; u < B; u++) { xin[u] = pi[u * LW]; xdel[u] = pd[u * LW]; }
+                for (int u = 0; u < B; u += 2) {
+                    const float2 a = ld2(fin, slot * B + u), d2 = ld2(fin, s0 + u);
+                    xin[u] = a.x; xin[u + 1] = a.y; xdel[u] = d2.x; xdel[u + 1] = d2.y;
+                }
 #pragma unroll
                 for (int u = 0; u < B; u++) {
                     const float old = R[sb + u];
@@ -640,20 +667,15 @@ k_boxqf(const float* __restrict__ srcW, unsigned img_gap, float* __restrict__ ds
                     for (int u = 0; u < B; u++) ob[u * LW] = o[u];
                 } else {
                     const bool whole = t0 >= keep_lo && t0 + B <= keep_hi && b >= 0;
-                    float* po = fout + (size_t)(oslot * B) * LW + lane;
-                    if (whole) {
+                    if (!whole) {
 #pragma unroll
-                        for (int u = 0; u < B; u++) po[u * LW] = o[u];
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < B; u++) {
-                            o[u] = (t0 + u >= keep_lo && t0 + u < keep_hi) ? o[u] : 0.0f;
-                            po[u * LW] = o[u];
-                        }
+                        for (int u = 0; u < B; u++) o[u] = (t0 + u >= keep_lo && t0 + u < keep_hi) ? o[u] : 0.0f;
                     }
+#pragma unroll
+                    for (int u = 0; u < B; u += 2) st2(fout, oslot * B + u, lane, o[u], o[u + 1]);
                     if (oslot == 0) {
 #pragma unroll
-                        for (int u = 0; u < B; u++) po[(3 * B + u) * LW] = o[u];
+                        for (int u = 0; u < B; u += 2) st2(fout, 3 * B + u, lane, o[u], o[u + 1]);
                     }
                 }
                 slot = slot == nf - 1 ? 0 : slot + 1;

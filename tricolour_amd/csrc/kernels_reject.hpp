@@ -41,7 +41,7 @@
 
 // per-process statistics (test hook tri_medrej_stats): blocks run, blocks that fell back before the pass (nothing to predict
 // from), after it (median outside the window / a list overflowing), at the bracket verification
-__device__ unsigned long long g_medrej_stats[4];
+__device__ unsigned long long g_medrej_stats[20];      // [4 + r]: blocks of the tile-parallel form (K3t) redone for reason r; [3] also its second rounds
 
 __global__ void __launch_bounds__(256)
 k_median_reject(const float* __restrict__ resid, const uint8_t* __restrict__ flags_in, uint8_t* __restrict__ flags_out,
@@ -68,6 +68,7 @@ k_median_reject(const float* __restrict__ resid, const uint8_t* __restrict__ fla
     const size_t oidx = win * (size_t)G + g;
     if (redo_status) {
         if (redo_status[win * redo_ws + (size_t)g * redo_stride + redo_word] != 0u) return;   // (uniform: nothing writes it during this launch)
+        if (threadIdx.x == 0) atomicAdd(&g_medrej_stats[4 + (redo_status[win * redo_ws + (size_t)g * redo_stride + redo_word + 2] & 15u)], 1ull);
         force_fallback = 1;
     }
     if (nrows <= 0) {

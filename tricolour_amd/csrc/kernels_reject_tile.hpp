@@ -17,18 +17,28 @@
 //                                   to the TF4 image
 //   k_mr_finish   (G, W)            per block: median's bin from the histogram, exact select over the window keys, bracket
 //                                   verification, the undecided samples against the exact threshold (byte stores)
-//   k_median_reject (G, W)          the blocks that failed any check (status word), redone from the input flags (K3r's fallback)
+//   k_mr_pass / k_mr_finish again   ROUND 2 for the blocks whose median fell outside the window or the decision bracket: the
+//                                   histogram is complete, so the bin of the median is now KNOWN -- the window becomes that bin
+//                                   +- 1 and the same two kernels run once more over those blocks' tiles only (all other
+//                                   workgroups leave at once); a block redone by ONE workgroup costs 1.8 ms of tail per launch
+//   k_median_reject (G, W)          whatever still fails (list overflow, nothing to predict from): redone from the input flags by
+//                                   one workgroup per block (K3r's fallback)
+// Block status: 1 = round 1, 2 = round 2, 3 = done, 0 = redo by k_median_reject.
 // Tiles are chunk-aligned (a tile never straddles two blocks): grid.y enumerates (chunk, 64-row group of the chunk).
 // 7 B / sample in k_mr_pass, ~0.3 in the other kernels, against 12.2 for k_median2 + k_reject4_t.
 // ---------------------------------------------------------------------------
 #ifndef MRT_CWIN
-#define MRT_CWIN 5u                      // half-width (bins) of the candidate window around the predicted bin
+#define MRT_CWIN 4u                      // half-width (bins) of the candidate window around the predicted bin
 #endif
 #ifndef MRT_DWIN
-#define MRT_DWIN 3u                      // half-width of the decision bracket (<= MRT_CWIN)
+#define MRT_DWIN 2u                      // half-width of the decision bracket (<= MRT_CWIN)
 #endif
-#define MRT_WCAND 320                    // window keys a WAVE of a tile can hold in LDS (4096 samples: ~4 % expected)
-#define MRT_WUND 128                     // undecided samples (index, value) per wave and tile (~1.5 % expected)
+#ifndef MRT_WCAND
+#define MRT_WCAND 384                    // window keys a WAVE of a tile can hold in LDS (4096 samples: ~4 % expected)
+#endif
+#ifndef MRT_WUND
+#define MRT_WUND 192                     // undecided samples (index, value) per wave and tile (~1.5 % expected)
+#endif
 #define MRT_PARW 16                      // words of a block's parameter record
 struct MrtPar {                          // (global memory, one per block; written by k_mr_predict, counters by k_mr_pass)
     unsigned lo, S, wlo, whi;            // histogram map, candidate window (bins)
@@ -69,7 +79,7 @@ k_mr_predict(const float* __restrict__ resid, const uint8_t* __restrict__ flags_
     const int c0 = (int)chunk_ends[g], c1 = (int)chunk_ends[g + 1];
     const int64_t len = (int64_t)(c1 - c0) * C4 * 4;
     auto give_up = [&]() {
-        if (tid == 0) { MrtPar p{}; p.status = 0; p.wlo = 1; p.whi = 0; p.thrA = 0.0; p.thrB = 0.0; *par = p; }
+        if (tid == 0) { MrtPar p{}; p.status = 0; p.wlo = 1; p.whi = 0; p.thrA = 0.0; p.thrB = 0.0; p.pad[1] = 1; *par = p; }   // (pad[1]: why the block is redone)
     };
     if (force_fallback || len < 65536) { give_up(); return; }
     const float* dblk = resid + win * ws_resid + (size_t)c0 * C4 * 4;
@@ -77,26 +87,31 @@ k_mr_predict(const float* __restrict__ resid, const uint8_t* __restrict__ flags_
     if (tid == 0) { sh_lo = 0xFFFFFFFFu; sh_hi = 0; }
     __syncthreads();
     const int64_t rstep = len / 64;
-    unsigned keys[64 / 8];                                              // (the runs are read once: 8 samples per thread and pass kept)
+    unsigned keys[64];                                                  // the runs are read ONCE: 64 samples per thread (flagged: all ones)
     {
         unsigned kmin = 0xFFFFFFFFu, kmax = 0;
-#pragma unroll 8
+#pragma unroll
         for (int rr = 0; rr < 64; rr++) {
             const int64_t i = rr * rstep + tid;
-            if (!fblk[i]) {
-                const unsigned k = __float_as_uint(dblk[i]) & 0x7FFFFFFFu;
-                kmin = min(kmin, k);
-                kmax = max(kmax, k);
-            }
+            const unsigned k = __float_as_uint(dblk[i]) & 0x7FFFFFFFu;
+            keys[rr] = fblk[i] ? 0xFFFFFFFFu : k;
         }
-        (void)keys;
+#pragma unroll
+        for (int rr = 0; rr < 64; rr++) {
+            if (keys[rr] != 0xFFFFFFFFu) { kmin = min(kmin, keys[rr]); kmax = max(kmax, keys[rr]); }
+        }
         kmin = ~wave_max_u32(~kmin);
         kmax = wave_max_u32(kmax);
         if (lane == 0) { atomicMin(&sh_lo, kmin); atomicMax(&sh_hi, kmax); }
     }
     __syncthreads();
-    const unsigned lo = sh_lo, hi = sh_hi;
+    unsigned lo = sh_lo;
+    const unsigned hi = sh_hi;
     if (hi < lo) { give_up(); return; }
+    // (the bins are linear in the KEY, i.e. logarithmic in the value: one exactly-zero sample would stretch them over the whole
+    //  exponent range -- 1/8 octave each, 40 % of the samples inside the window.  The histogram covers the top 16 octaves of the
+    //  sample; everything below counts into bin 0, where a median is not expected -- and the checks catch it if it is there.)
+    if (hi > (16u << 23) && lo < hi - (16u << 23)) lo = hi - (16u << 23);
     int S = 0;
     {
         const unsigned span = hi - lo;
@@ -105,11 +120,10 @@ k_mr_predict(const float* __restrict__ resid, const uint8_t* __restrict__ flags_
 #pragma unroll
     for (int u = 0; u < SEL_BINS / 256; u++) hist[u * 256 + tid] = 0;
     __syncthreads();
-#pragma unroll 8
+#pragma unroll
     for (int rr = 0; rr < 64; rr++) {
-        const int64_t i = rr * rstep + tid;
-        if (!fblk[i]) {
-            const unsigned k = __float_as_uint(dblk[i]) & 0x7FFFFFFFu;
+        const unsigned k = keys[rr];
+        if (k != 0xFFFFFFFFu) {
             const unsigned b = k < lo ? 0u : min(((k - lo) >> S) + 1u, 2047u);
             atomicAdd(&hist[b], 1u);
         }
@@ -156,10 +170,14 @@ k_mr_predict(const float* __restrict__ resid, const uint8_t* __restrict__ flags_
         const unsigned bp = sh_bin;
         MrtPar p{};
         p.lo = lo; p.S = (unsigned)S;
-        p.wlo = bp > MRT_CWIN + 1u ? bp - MRT_CWIN : 1u;
-        p.whi = bp + MRT_CWIN < 2046u ? bp + MRT_CWIN : 2046u;
-        const unsigned dlo = bp > MRT_DWIN + 1u ? bp - MRT_DWIN : 1u;
-        const unsigned dhi = bp + MRT_DWIN < 2046u ? bp + MRT_DWIN : 2046u;
+        // window widths are RELATIVE (the prediction is good to ~1 % of the value whatever the bin width): MRT_CWIN / MRT_DWIN bins
+        // of 1/64 octave (S = 17), scaled to the bins this block has
+        const unsigned cw = S >= 17 ? max(MRT_CWIN >> (S - 17), 2u) : min(MRT_CWIN << (17 - S), 200u);
+        const unsigned dw = S >= 17 ? max(MRT_DWIN >> (S - 17), 1u) : min(MRT_DWIN << (17 - S), 100u);
+        p.wlo = bp > cw + 1u ? bp - cw : 1u;
+        p.whi = bp + cw < 2046u ? bp + cw : 2046u;
+        const unsigned dlo = bp > dw + 1u ? bp - dw : 1u;
+        const unsigned dhi = bp + dw < 2046u ? bp + dw : 2046u;
         const unsigned long long kB64 = (unsigned long long)lo + ((unsigned long long)dhi << S) - 1ull;
         const unsigned kA = lo + ((dlo - 1u) << S), kB = kB64 > 0x7F7FFFFFull ? 0x7F7FFFFFu : (unsigned)kB64;
         p.thrA = (double)__uint_as_float(kA) * scale;
@@ -174,7 +192,7 @@ k_mr_predict(const float* __restrict__ resid, const uint8_t* __restrict__ flags_
 __global__ void __launch_bounds__(256)
 k_mr_pass(const float* __restrict__ resid, const uint8_t* __restrict__ flags_in, uint8_t* __restrict__ flags_out,
           uint8_t* __restrict__ flags_t4, const int64_t* __restrict__ chunk_ends, int L, int C4, int G,
-          size_t ws_resid, size_t ws_flags, unsigned* __restrict__ gscratch, size_t scratch_ws, size_t ccap, size_t ucap) {
+          size_t ws_resid, size_t ws_flags, unsigned* __restrict__ gscratch, size_t scratch_ws, size_t ccap, size_t ucap, unsigned round) {
     __shared__ unsigned hist[SEL_BINS + 64];
     __shared__ unsigned tile[64][65];
     __shared__ unsigned lcand[4][MRT_WCAND];
@@ -200,7 +218,7 @@ k_mr_pass(const float* __restrict__ resid, const uint8_t* __restrict__ flags_in,
     __shared__ unsigned sh_status;
     if (tid == 0) sh_status = __hip_atomic_load(&par->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (!sh_status) return;                                            // (uniform) the block is redone by the fallback kernel
+    if (sh_status != round) return;                                    // (uniform) not this round's block
     const unsigned lo = par->lo, S = par->S, wlo = par->wlo, wspan = par->whi - par->wlo;
     const double thrA = par->thrA, thrB = par->thrB;
     const int w0 = blockIdx.x * 64, w = w0 + tx;
@@ -247,6 +265,15 @@ k_mr_pass(const float* __restrict__ resid, const uint8_t* __restrict__ flags_in,
                 const unsigned pos = ccnt + __builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u));
                 if (inwin && pos < MRT_WCAND) lcand[wave][pos] = k;
                 ccnt += (unsigned)__builtin_popcountll(cm);
+                if (ccnt > MRT_WCAND) {                                 // (uniform, rare) this wave's LDS list is full: straight to the block's list
+                    const bool sp = inwin && pos >= MRT_WCAND;
+                    const unsigned long long sm = __builtin_amdgcn_ballot_w64(sp);
+                    unsigned b2 = 0;
+                    if (lane == 0 && sm) b2 = atomicAdd(&par->ncand, (unsigned)__builtin_popcountll(sm));
+                    b2 = (unsigned)__builtin_amdgcn_readfirstlane((int)b2);
+                    const size_t at = (size_t)b2 + __builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u));
+                    if (sp && at < ccap) lay.cand(g)[at] = k;
+                }
             }
             const double dx = (double)xv[k4];
             const bool gtB = dx > thrB, gtA = dx > thrA;               // (a NaN compares false twice: never flagged)
@@ -255,20 +282,32 @@ k_mr_pass(const float* __restrict__ resid, const uint8_t* __restrict__ flags_in,
             const unsigned long long um = __builtin_amdgcn_ballot_w64(und);
             if (um) {
                 const unsigned pos = ucnt + __builtin_amdgcn_mbcnt_hi((unsigned)(um >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)um, 0u));
-                if (und && pos < MRT_WUND) lund[wave][pos] = make_uint2(i * 4u + (unsigned)k4, __float_as_uint(xv[k4]));
+                const uint2 ent = make_uint2(i * 4u + (unsigned)k4, __float_as_uint(xv[k4]));
+                if (und && pos < MRT_WUND) lund[wave][pos] = ent;
                 ucnt += (unsigned)__builtin_popcountll(um);
+                if (ucnt > MRT_WUND) {                                  // (uniform, rare: a tile full of samples near the threshold)
+                    const bool sp = und && pos >= MRT_WUND;
+                    const unsigned long long sm = __builtin_amdgcn_ballot_w64(sp);
+                    unsigned b2 = 0;
+                    if (lane == 0 && sm) b2 = atomicAdd(&par->nund, (unsigned)__builtin_popcountll(sm));
+                    b2 = (unsigned)__builtin_amdgcn_readfirstlane((int)b2);
+                    const size_t at = (size_t)b2 + __builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u));
+                    if (sp && at < ucap) reinterpret_cast<uint2*>(lay.und(g))[at] = ent;
+                }
             }
         }
         __builtin_amdgcn_raw_buffer_store_b32(fn, fors, (int)(valid ? i * 4u : OOBR), 0, 0);
         tile[ty + 4 * q][tx] = fn;
     }
-    over = ccnt > MRT_WCAND || ucnt > MRT_WUND;
+    over = false;                                                       // (a full wave list spills to the block's list: nothing fails here)
+    ccnt = min(ccnt, (unsigned)MRT_WCAND);                              // what is left in LDS
+    ucnt = min(ucnt, (unsigned)MRT_WUND);
     mb1 = wave_max_u32(mb1);
     // this wave's lists to the block's: one reservation each
     unsigned cbase = 0, ubase = 0;
     if (lane == 0) {
         if (mb1) atomicMax(&par->below1, mb1);
-        if (over) atomicExch(&par->status, 0u);                         // a wave's list overflowed: the block is redone
+        if (over) { atomicExch(&par->status, 0u); par->pad[1] = 2 + (ccnt > MRT_WCAND ? 0 : 8); }   // a wave's list overflowed: the block is redone
         if (ccnt && !over) cbase = atomicAdd(&par->ncand, ccnt);
         if (ucnt && !over) ubase = atomicAdd(&par->nund, ucnt);
     }
@@ -280,12 +319,14 @@ k_mr_pass(const float* __restrict__ resid, const uint8_t* __restrict__ flags_in,
         const int wq = w0 + j, l = l0 + tx;
         if (l < c1 && wq < C4) ft[(size_t)wq * L + l] = tile[tx][j];
     }
-    // histogram: one atomic per occupied bin
-    unsigned* ghist = lay.hist(g);
+    // histogram: one atomic per occupied bin (round 2: the block's histogram is already complete)
+    if (round == 1) {
+        unsigned* ghist = lay.hist(g);
 #pragma unroll
-    for (int u = 0; u < SEL_BINS / 256; u++) {
-        const unsigned h = hist[u * 256 + tid];
-        if (h) atomicAdd(&ghist[u * 256 + tid], h);
+        for (int u = 0; u < SEL_BINS / 256; u++) {
+            const unsigned h = hist[u * 256 + tid];
+            if (h) atomicAdd(&ghist[u * 256 + tid], h);
+        }
     }
     if (!over) {
         unsigned* gc = lay.cand(g);
@@ -299,8 +340,9 @@ k_mr_pass(const float* __restrict__ resid, const uint8_t* __restrict__ flags_in,
 
 // ---- finish: one workgroup per block ------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_mr_finish(uint8_t* __restrict__ flags_out, uint8_t* __restrict__ flags_t4, double* __restrict__ med, double scale, int L, int C4, int G,
-            size_t ws_flags, unsigned* __restrict__ gscratch, size_t scratch_ws, size_t ccap, size_t ucap) {
+k_mr_finish(const float* __restrict__ resid, const uint8_t* __restrict__ flags_in, uint8_t* __restrict__ flags_out,
+            uint8_t* __restrict__ flags_t4, double* __restrict__ med, const int64_t* __restrict__ chunk_ends, double scale, int L, int C4, int G,
+            size_t ws_resid, size_t ws_flags, unsigned* __restrict__ gscratch, size_t scratch_ws, size_t ccap, size_t ucap, unsigned round) {
     __shared__ unsigned hist[SEL_BINS];
     __shared__ unsigned sh[9];
     __shared__ unsigned sh_bin, sh_exc, sh_excw;
@@ -309,7 +351,7 @@ k_mr_finish(uint8_t* __restrict__ flags_out, uint8_t* __restrict__ flags_t4, dou
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const MrtLayout lay{gscratch + win * scratch_ws, G, ccap, ucap};
     MrtPar* par = lay.par(g);
-    if (!par->status) return;                                          // (uniform: nothing writes it while this kernel runs but this workgroup) redone by the fallback kernel
+    if (par->status != round) return;                                  // (uniform: nothing writes it while this kernel runs but this workgroup)
     const unsigned wlo = par->wlo, whi = par->whi, nc = par->ncand, nu = par->nund, below1 = par->below1;
     const double thrA = par->thrA, thrB = par->thrB;
     const unsigned* ghist = lay.hist(g);
@@ -362,8 +404,28 @@ k_mr_finish(uint8_t* __restrict__ flags_out, uint8_t* __restrict__ flags_t4, dou
     }
     __syncthreads();
     const unsigned bsel = sh_bin, excw = sh_excw;
-    auto fail = [&]() { if (tid == 0) par->status = 0; };
-    if (!(total > 0 && bsel >= wlo && bsel <= whi && nc <= ccap && nu <= ucap)) { fail(); return; }
+    auto fail = [&](unsigned why) { if (tid == 0) { par->status = 0; par->pad[1] = why; } };
+    // Round 2 set-up: the histogram says which bin holds the median -- window and decision bracket become that bin +- 1
+    auto second_round = [&]() {
+        if (tid == 0) {
+            const unsigned lo = par->lo, S = par->S;
+            const unsigned nlo = bsel > 2u ? bsel - 1u : 1u, nhi = bsel + 1u < 2046u ? bsel + 1u : 2046u;
+            const unsigned long long kB64 = (unsigned long long)lo + ((unsigned long long)nhi << S) - 1ull;
+            const unsigned kA = lo + ((nlo - 1u) << S), kB = kB64 > 0x7F7FFFFFull ? 0x7F7FFFFFu : (unsigned)kB64;
+            par->wlo = nlo; par->whi = nhi;
+            par->thrA = (double)__uint_as_float(kA) * scale;
+            par->thrB = (double)__uint_as_float(kB) * scale;
+            par->ncand = 0; par->nund = 0; par->below1 = 0;
+            par->pad[0] += 1;                                           // (statistics: rounds beyond the first)
+            atomicAdd(&g_medrej_stats[3], 1ull);
+            par->status = 2;
+        }
+    };
+    if (!(total > 0 && nc <= ccap && nu <= ucap && bsel >= 1 && bsel <= 2046)) { fail(total == 0 ? 3u : (bsel < 1 || bsel > 2046 ? 4u : 5u)); return; }
+    if (!(bsel >= wlo && bsel <= whi)) {                               // the median is outside the window
+        if (round == 1) second_round(); else fail(6u);
+        return;
+    }
     __syncthreads();   // sh[] is reused by select3 below
     const unsigned* gcand = lay.cand(g);
     auto enumerate_gc = [&](auto&& visit) {
@@ -391,8 +453,12 @@ k_mr_finish(uint8_t* __restrict__ flags_out, uint8_t* __restrict__ flags_t4, dou
         m = (double)sm / 2.0;
     }
     const double thr = m * scale;
-    if (!(thr >= thrA && thr <= thrB)) { fail(); return; }
     if (tid == 0) med[win * (size_t)G + g] = m;
+    if (!(thr >= thrA && thr <= thrB)) {
+        // the exact median lies outside the DECISION bracket: the pass's decisions cannot be trusted
+        if (round == 1) second_round(); else fail(7u);
+        return;
+    }
     // the undecided samples against the exact threshold
     const uint2* gu = reinterpret_cast<const uint2*>(lay.und(g));
     uint8_t* fo8 = flags_out + win * ws_flags;
@@ -406,4 +472,5 @@ k_mr_finish(uint8_t* __restrict__ flags_out, uint8_t* __restrict__ flags_t4, dou
             ft8[((size_t)(t >> 2) * L + l) * 4 + (t & 3u)] = 1;
         }
     }
+    if (tid == 0) par->status = 3;                                      // done
 }

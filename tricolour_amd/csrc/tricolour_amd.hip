@@ -3,7 +3,8 @@
 //   tri_common.hpp            overview, error plumbing, device helpers
 //   kernels_elementwise.hpp   K1, K2, K5, K6, K8, pack / unpack, strategy steps
 //   kernels_median.hpp        K3  exact medians
-//   kernels_reject.hpp        K3r block median + rejection of the background loop in one pass
+//   kernels_reject.hpp        K3r block median + rejection of the background loop in one pass (one workgroup per block; the redo path)
+//   kernels_reject_tile.hpp   K3t the same, tile-parallel: predict / pass / finish
 //   kernels_boxfilter.hpp     K4  box-Gaussian filter (four forms)
 //   kernels_boxline.hpp / kernels_boxpipe.hpp   K4r register delay lines, K4p / K4q / K4qf stage pipelines
 //   kernels_boxweight.hpp     K4w integer weight image of the time-axis stage (bit / byte / halfword-packed delay lines)
@@ -14,6 +15,7 @@
 #include "kernels_elementwise.hpp"
 #include "kernels_median.hpp"
 #include "kernels_reject.hpp"
+#include "kernels_reject_tile.hpp"
 #include "kernels_boxfilter.hpp"
 #include "kernels_boxline.hpp"
 #include "kernels_boxpipe.hpp"
@@ -1580,6 +1582,34 @@ int background2d(const Run& r, bool flagsFT_current) {
                 if (rc) return rc;
             }
             static const bool no_fuse = [] { const char* e = getenv("TRI_NO_FUSED_REJECT"); return e && e[0] == '1'; }();
+            static const bool no_tile = [] { const char* e = getenv("TRI_NO_TILE_MEDREJ"); return e && e[0] == '1'; }();
+            if (r.pl.vec && wsB % 4 == 0 && wsA % 4 == 0 && packed && !no_fuse && !no_tile && no_medrej && G <= 65535) {
+                // K3t: median + rejection + TF4 re-pack in one pass over |data - background|, tile-parallel (kernels_reject_tile.hpp):
+                // predict (per block) -> pass (per 64 x 64-word tile) -> finish (per block) -> redo of the blocks that failed a check.
+                // Scratch: the dead time-stage images of the window.
+                const size_t nb = (size_t)pl.maxchunk * T;                 // samples of the largest block
+                const size_t ccap = (nb / 4) & ~(size_t)3, ucap = (nb / 8) & ~(size_t)3;
+                int ytiles = 0;
+                for (int g = 0; g < G; g++) ytiles += (int)cdiv(r.p->chunk_ends[g + 1] - r.p->chunk_ends[g], 64);
+                // (blocks too small to predict from -- fewer than 65536 samples -- would all take the redo path: the two kernels below)
+                if (mrt_scratch_words(G, ccap, ucap) <= wsA && (medrej_fallback || (pl.maxchunk - 1) * (int64_t)T >= 65536) && ytiles > 0 && ytiles <= 65535) {
+                    unsigned* sc = reinterpret_cast<unsigned*>(ws.Aw);
+                    hipLaunchKernelGGL(k_mr_predict, dim3((unsigned)G, (unsigned)W), dim3(256), 0, r.st, (const float*)ws.Bo, (const uint8_t*)cur_ft,
+                                       ws.d_chunk_ends, rej, T / 4, G, wsB, N, sc, wsA, ccap, ucap, medrej_fallback);
+                    for (unsigned round = 1; round <= 2; round++) {        // (round 2: only the blocks whose median missed the predicted window)
+                        hipLaunchKernelGGL(k_mr_pass, dim3((unsigned)cdiv(T / 4, 64), (unsigned)ytiles, (unsigned)W), dim3(256), 0, r.st, (const float*)ws.Bo,
+                                           (const uint8_t*)cur_ft, alt_ft, ws.bgfTF, ws.d_chunk_ends, Fa, T / 4, G, wsB, N, sc, wsA, ccap, ucap, round);
+                        hipLaunchKernelGGL(k_mr_finish, dim3((unsigned)G, (unsigned)W), dim3(256), 0, r.st, (const float*)ws.Bo, (const uint8_t*)cur_ft, alt_ft,
+                                           ws.bgfTF, ws.med, ws.d_chunk_ends, rej, Fa, T / 4, G, wsB, N, sc, wsA, ccap, ucap, round);
+                    }
+                    hipLaunchKernelGGL(k_median_reject, dim3((unsigned)G, (unsigned)W), dim3(256), 0, r.st, (const float*)ws.Bo, (const uint8_t*)cur_ft,
+                                       alt_ft, ws.bgfTF, ws.med, ws.d_chunk_ends, rej, Fa, T / 4, G, wsB, N, sc, wsA, 0u, 0u, 1,
+                                       (const unsigned*)sc, wsA, (int)MRT_PARW, 11);
+                    LAUNCHCHK();
+                    std::swap(cur_ft, alt_ft);
+                    continue;
+                }
+            }
             {
                 // one pass: median + rejection + TF4 re-pack (K3r).  Scratch per (window, chunk) block: the dead time-stage
                 // images, half for the window's keys, half for the undecided samples' indices
@@ -2136,7 +2166,10 @@ extern "C" int tri_bench_sumthreshold(const float* data, const double* mad, uint
     if (variant == 5) {
         HIPCHK(hipMalloc(&pdata, (size_t)n_win * ws * sizeof(float)));
         HIPCHK(hipMalloc(&pout, (size_t)n_win * ws));
+        const bool klog = g_klog_on;
+        g_klog_on = false;                                   // (re-layout helpers are not part of what is measured)
         hipLaunchKernelGGL(k_panelize<float>, dim3((unsigned)cdiv((int64_t)ws, 256), (unsigned)n_win), dim3(256), 0, st, data, pdata, L, C, ws);
+        g_klog_on = klog;
         LAUNCHCHK();
     }
     if (variant == 4) {
@@ -2169,7 +2202,10 @@ extern "C" int tri_bench_sumthreshold(const float* data, const double* mad, uint
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (variant == 5) {
+        const bool klog = g_klog_on;
+        g_klog_on = false;
         hipLaunchKernelGGL(k_unpanel_w<uint8_t>, dim3((unsigned)cdiv((int64_t)ws, 256), (unsigned)n_win), dim3(256), 0, st, (const uint8_t*)pout, out, L, C, ws);
+        g_klog_on = klog;
         LAUNCHCHK();
         HIPCHK(hipStreamSynchronize(st));
         (void)hipFree(pdata);
@@ -2331,15 +2367,15 @@ extern "C" int tri_kernel_log(int op, char* buf, int64_t cap) {
 
 // Test hook: statistics of the fused median + rejection kernel (K3r) since the last reset: blocks run, fallbacks before the
 // pass, after it, at the bracket verification.
-extern "C" int tri_medrej_stats(uint64_t* out4, int reset) {
-    unsigned long long h[4] = {0, 0, 0, 0};
+extern "C" int tri_medrej_stats(uint64_t* out20, int reset) {
+    unsigned long long h[20] = {0};
     HIPCHK(hipDeviceSynchronize());
-    if (out4) {
+    if (out20) {
         HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_medrej_stats), sizeof(h)));
-        for (int k = 0; k < 4; k++) out4[k] = h[k];
+        for (int k = 0; k < 20; k++) out20[k] = h[k];
     }
     if (reset) {
-        unsigned long long z[4] = {0, 0, 0, 0};
+        unsigned long long z[20] = {0};
         HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_medrej_stats), z, sizeof(z)));
     }
     return TRI_OK;
