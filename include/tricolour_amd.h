@@ -354,13 +354,15 @@ int tri_sum_threshold_flagger_debug(const void *vis, int vis_dtype,
  * (n_win, rows, row_len) float32 array; segments [seg_ends[g], seg_ends[g+1])
  * (HOST array) along each row; med is (n_win, rows, n_seg_ends - 1) float64,
  * NaN where a segment has no unflagged sample.  variant 0 = automatic,
- * 1 = wave kernel, 2 / 3 = three-pass workgroup kernel with scalar / vector loads,
+ * 1 = wave kernel (4: its 16-byte-load form over masked groups), 2 / 3 = three-pass workgroup kernel with scalar / vector loads,
  * 5 / 6 = two-pass workgroup kernel with vector / scalar loads, 7 = two-pass
  * kernel, vector loads over segments that need not be 4-aligned (row_len % 4 == 0),
  * 8 = multi-workgroup two-pass select (one segment spanning the row),
  * 9 / 10 = the two-pass select with the predicted-bin candidate window in
  * global scratch (one read of the segment when the prediction holds;
- * 9 vector loads, 10 scalar).
+ * 9 vector loads, 10 scalar).  1 / 4 run the wave kernels with several rows of a
+ * segment per wave (the flagger's launch shape), 11 / 14 with one segment per
+ * wave (TRI_MEDIAN_WAVE_OLD=1 in the flagger).
  * Restates _median_abs / _median_abs_axis0 (flagging.py:267-304).
  */
 int tri_test_median(const float *data, const uint8_t *flags, double *med,

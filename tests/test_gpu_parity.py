@@ -526,16 +526,16 @@ def _np_median_abs(vals):
 
 
 @pytest.mark.parametrize("rows,row_len,ends,variants", [
-    (5, 1024, [0, 1024], (1, 2, 3)),
-    (3, 1000, [0, 1000], (1, 2, 3)),
-    (2, 772, [0, 772], (1,)),
-    (3, 410, [0, 41, 82, 123, 410], (1, 2)),
-    (3, 4096, [0, 409, 819, 1228, 1638, 2048, 2457, 2867, 3276, 3686, 4096], (1, 4)),
-    (2, 1024, [3, 1021], (1, 4)),
-    (2, 64, [1, 2, 7, 61, 64], (1, 4)),
+    (5, 1024, [0, 1024], (1, 2, 3, 11)),
+    (3, 1000, [0, 1000], (1, 2, 3, 11)),
+    (2, 772, [0, 772], (1, 11)),
+    (3, 410, [0, 41, 82, 123, 410], (1, 2, 11)),
+    (3, 4096, [0, 409, 819, 1228, 1638, 2048, 2457, 2867, 3276, 3686, 4096], (1, 4, 11, 14)),
+    (2, 1024, [3, 1021], (1, 4, 11, 14)),
+    (2, 64, [1, 2, 7, 61, 64], (1, 4, 11, 14)),
     (2, 4096, [0, 4, 8, 2048, 4096], (2, 3)),
     (1, 6000, [0, 1, 2, 3001, 6000], (2,)),
-    (4, 64, [0, 0, 1, 2, 64], (1, 2)),
+    (4, 64, [0, 0, 1, 2, 64], (1, 2, 11)),
     (1, 300000, [0, 100000, 300000], (2, 3, 5, 6)),
     (2, 4096, [0, 4, 8, 2048, 4096], (5, 6)),
     (3, 40000, [0, 4000, 4004, 40000], (5, 6)),
@@ -579,6 +579,60 @@ def test_median_kernels(gpu, rows, row_len, ends, variants):
         got = med.cpu().numpy()
         same = (got == exp) | (np.isnan(got) & np.isnan(exp))
         assert same.all(), "variant %d: %d medians differ" % (variant, (~same).sum())
+
+
+@pytest.mark.parametrize("row_len,ends", [(512, [0, 512]), (1024, [0, 1024]), (2048, [0, 409, 819, 1228, 1640, 2048])])
+def test_median_wave_corners(gpu, row_len, ends):
+    """The wave medians (kernels_median.hpp k_median_wave; several rows of a segment per wave in variants 1 / 4, one segment
+    per wave in 11) on keys laid out to hit every branch of the radix select: key spreads of 7 ... 20 bits (one to three
+    digits, a short last digit), 63 ... 130 keys sharing the median's first-digit bin, duplicates straddling the median rank,
+    the lower middle element alone in a lower bin, odd and even counts, row counts that do not divide by the rows per wave."""
+    import ctypes as C
+    import torch
+    from tricolour_amd import _lib
+    rs = np.random.RandomState(row_len)
+    base = np.float32(1.5).view(np.uint32)
+    rows = []
+
+    def from_offsets(off):
+        return (base + off.astype(np.uint32)).view(np.float32) * rs.choice(np.float32([-1, 1]), size=off.size)
+
+    for bits in (7, 8, 9, 10, 11, 12, 20):
+        rows.append(from_offsets(rs.randint(0, 1 << bits, size=row_len)))
+    for dup in (63, 64, 65, 66, 130):
+        # `dup` keys share the bin of the median (spread 2^20: bins of 1024 key values), the others lie well outside it
+        for shift in (0, 1):
+            off = np.concatenate([rs.randint(0, 1 << 19, size=(row_len - dup) // 2 + shift),
+                                  (1 << 19) + rs.randint(0, 1000, size=dup),
+                                  (1 << 19) + 4096 + rs.randint(0, 1 << 19, size=row_len - dup - (row_len - dup) // 2 - shift)])
+            off[0], off[-1] = 0, (1 << 20) - 1
+            rows.append(from_offsets(rs.permutation(off)))
+    # equal keys around the median rank; the lower middle element alone in a lower bin
+    off = rs.randint(0, 1 << 16, size=row_len); off[: row_len // 3] = 1 << 15
+    rows.append(from_offsets(off))
+    off = np.concatenate([np.full(row_len // 2, 5), np.full(row_len - row_len // 2, 5 + (1 << 14))]); off[0] = 0; off[-1] = 1 << 15
+    rows.append(from_offsets(off))
+    data = np.stack(rows + rows[:3])[None].astype(np.float32)       # (21 rows: a ragged last block of rows per wave)
+    data = np.concatenate([data, data[:, :, ::-1]], axis=0)
+    flags = np.zeros(data.shape, dtype=bool)
+    flags[1] = rs.uniform(size=data.shape[1:]) < 0.01          # shifts the ranks by a few, odd / even counts
+    flags[1, :, 5] = True
+    G = len(ends) - 1
+    n_win, R = data.shape[:2]
+    exp = np.empty((n_win, R, G))
+    for w in range(n_win):
+        for r in range(R):
+            for g in range(G):
+                seg = slice(ends[g], ends[g + 1])
+                exp[w, r, g] = _np_median_abs(data[w, r, seg][~flags[w, r, seg]])
+    d = torch.from_numpy(np.ascontiguousarray(data)).cuda()
+    f = torch.from_numpy(flags).cuda().view(torch.uint8)
+    e = (C.c_int64 * len(ends))(*ends)
+    for variant in ((1, 11) if max(np.diff(ends)) + 3 > 1024 else (1, 4, 11)):
+        med = torch.full((n_win, R, G), -1.0, dtype=torch.float64, device="cuda")
+        _lib.check(_lib.lib().tri_test_median(d.data_ptr(), f.data_ptr(), med.data_ptr(), n_win, R, row_len, e, len(ends), variant, None))
+        got = med.cpu().numpy()
+        assert np.array_equal(got, exp), "variant %d: %d medians differ" % (variant, (got != exp).sum())
 
 
 EDGE_CASES = [
@@ -1093,7 +1147,7 @@ print("DIFF", bad)
                                   "TRI_NO_PACKED_FLAGS", "TRI_FILTER_MULTIPASS", "TRI_ST_GENERIC", "TRI_ST_REGISTER",
                                   "TRI_FILTER_DIRECT_FT", "TRI_FILTER_NO_REGRING", "TRI_FILTER_NO_REGRING_F", "TRI_MEDIAN_3PASS",
                                   "TRI_NO_FUSED_REJECT", "TRI_NO_FT_SPEC_OR", "TRI_NO_FUSED_BEGIN", "TRI_NO_FUSED_DILATE", "TRI_SPEC_NO_PIPE", "TRI_INTERP_ONE_PASS", "TRI_MEDIAN_NO_PREDICT", "TRI_FILTER_NO_PIPE_T", "TRI_FILTER_NO_PIPE_F", "TRI_ST_NO_PIPE",
-                                  "TRI_FILTER_NO_EXACT", "TRI_BOXX_NTI=256", "TRI_FILTER_NO_TF_REJECT", "TRI_FILTER_PIPE_T_B8=0", "TRI_FILTER_PIPE_F_B8=0", "TRI_NO_FUSED_OR", "TRI_FILTER_NO_BOXW", "TRI_ST_NO_PANEL", "TRI_FUSED_MEDREJ", "TRI_FUSED_MEDREJ=1;TRI_MEDREJ_FORCE_FALLBACK=1", "TRI_NO_TILE_MEDREJ", "TRI_MEDREJ_FORCE_FALLBACK",
+                                  "TRI_FILTER_NO_EXACT", "TRI_BOXX_NTI=256", "TRI_FILTER_NO_TF_REJECT", "TRI_FILTER_PIPE_T_B8=0", "TRI_FILTER_PIPE_F_B8=0", "TRI_NO_FUSED_OR", "TRI_FILTER_NO_BOXW", "TRI_ST_NO_PANEL", "TRI_FUSED_MEDREJ", "TRI_FUSED_MEDREJ=1;TRI_MEDREJ_FORCE_FALLBACK=1", "TRI_NO_TILE_MEDREJ", "TRI_MEDIAN_WAVE_OLD", "TRI_MEDREJ_FORCE_FALLBACK",
                                   "DEFAULT_ROUTES"])
 def test_alternate_kernel_paths(gpu, knob):
     """Every fallback / A-B path selectable through an environment knob (read once

@@ -41,6 +41,17 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     v = max(v, wave_dpp0<0x143, 0xC>(v));
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
+// inclusive prefix sum over the 64 lanes: four shifts inside the rows of 16, then the two row broadcasts (a ds_bpermute scan
+// makes six dependent round trips through the LDS crossbar -- the longest chain of a wave-median pass)
+__device__ __forceinline__ unsigned wave_scan_u32(unsigned v) {
+    v += wave_dpp0<0x111, 0xF>(v);     // row_shr:1 (lanes without a source add 0)
+    v += wave_dpp0<0x112, 0xF>(v);     // row_shr:2
+    v += wave_dpp0<0x114, 0xF>(v);     // row_shr:4
+    v += wave_dpp0<0x118, 0xF>(v);     // row_shr:8
+    v += wave_dpp0<0x142, 0xA>(v);     // row_bcast:15: rows 1 and 3 add the row before them
+    v += wave_dpp0<0x143, 0xC>(v);     // row_bcast:31: rows 2 and 3 add rows 0 + 1
+    return v;
+}
 #define SEL_BINS 2048
 // Three radix passes over the 31-bit key: digits of 11, 10 and 10 bits.  The
 // even-count partner (rank n/2 - 1) needs no extra pass: it equals the median
@@ -935,8 +946,19 @@ k_medbig_select(const float* __restrict__ data, const uint8_t* __restrict__ flag
 // grid (ceil(R*G/4), W), block 256
 // ---------------------------------------------------------------------------
 #define MW_K 16   // register slots per lane of the largest instantiation (segments <= 1024)
+#ifndef MW_SPW
+#define MW_SPW 8  // rows of one segment a wave walks (see k_median_wave): segments of <= 512 samples
+#endif
+#ifndef MW_SPW16
+#define MW_SPW16 1 // ... of <= 1024 samples (the loads already take 90 % of that kernel's time: 1 / 2 / 4 / 8 rows measured the same)
+#endif
 
-template <int KS, bool VEC4>   // KS register slots per lane: segments of at most 64 * KS samples
+// SPW (round 4): a wave takes SPW consecutive ROWS of one segment g -- the segment's start / length (two dependent scalar
+// loads), the row-independent part of every address and the four buffer descriptors are set up once per wave instead of once
+// per segment (that prologue was ~140 of a segment's ~770 instructions, with three scalar-memory round trips in a row), and
+// the loads of row j + 1 (raw words, OR-ed only when consumed) are issued before the select of row j.
+// grid (ceil(ceil(R / SPW) * G / 4), W), block 256
+template <int KS, bool VEC4, int SPW = 1>   // KS register slots per lane: segments of at most 64 * KS samples
 __global__ void __launch_bounds__(256)
 k_median_wave(const float* __restrict__ data, const uint8_t* __restrict__ flags,
               double* __restrict__ med, size_t WSd, size_t WSf, size_t RS, size_t ES,
@@ -951,58 +973,88 @@ k_median_wave(const float* __restrict__ data, const uint8_t* __restrict__ flags,
     // flagging.py:967-969 sees flags | time_flags | spec_flags without a pass that writes the union first.
     __shared__ unsigned hist[4][256];
     const unsigned SENT = 0xFFFFFFFFu;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int seg = blockIdx.x * 4 + wave;
-    const bool live = seg < R * G;
-    const int row = live ? seg / G : 0, g = live ? seg % G : 0;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;   // (row / segment indices in scalar registers)
+    const int wid = blockIdx.x * 4 + wave;                              // this wave's (row block, segment)
+    const int nrb = (R + SPW - 1) / SPW;
+    if (wid >= nrb * G) return;                                         // (no workgroup barrier below: waves are independent)
+    const int g = G == 1 ? 0 : wid % G, row0 = (G == 1 ? wid : wid / G) * SPW;
     const size_t win = blockIdx.y;
-    const int len = live ? (int)seg_len[g] : 0;
-    const size_t rel = (size_t)row * RS + (size_t)seg_start[g] * ES;
-    const float* d = data + win * WSd + rel;
-    const uint8_t* f = flags + win * WSf + rel;
-    const uint8_t* f2 = flags2 ? flags2 + win * WSf + rel : nullptr;
-    const uint8_t* cf = colflags ? colflags + win * WScol + (live ? (size_t)seg_start[g] : (size_t)0) : nullptr;
+    const int start = (int)seg_start[g], len = (int)seg_len[g];
+    const int mis = start & 3;
+    constexpr int NG = VEC4 ? KS / 4 : 1;
+    typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
+    struct Raw { u32x4 d[NG]; unsigned fa[NG], fb[NG], fc[NG]; };
+    // VEC4: the aligned 16-byte groups covering the segment (rows are 16-byte aligned and a multiple of 4 long; host:
+    // a window's image below 4 GB), samples outside the segment masked when the keys are built (a selection does not care
+    // which lane holds which sample).  Buffer loads, groups beyond the segment / rows beyond the image at an out-of-range
+    // offset (-> 0) and an absent flag image behind an EMPTY descriptor (-> 0): no branch between issuing a row and using it,
+    // so the hardware counter wait before the keys are built is for THIS row's loads only.
+    constexpr unsigned OOB = 0xfffffff0u;
+    const unsigned img = (unsigned)RS * (unsigned)(panel_rows > R ? panel_rows : R);   // elements of one window's image
+    const float* bd = data + win * WSd;
+    const uint8_t *bf = flags + win * WSf, *bf2 = flags2 ? flags2 + win * WSf : flags, *bc = colflags ? colflags + win * WScol : flags;
+    const unsigned nd = VEC4 ? img * 4u : 0u, nf = VEC4 ? img : 0u, nf2 = VEC4 && flags2 ? img : 0u, nc = VEC4 && colflags ? (unsigned)RS : 0u;
+    // per lane and group, row-independent: column (offset in a row of a plain image), offset in the data image's row / panel
+    unsigned lcol[NG], lpan[NG];
+#pragma unroll
+    for (int u4 = 0; u4 < NG; u4++) {
+        const int i = (u4 * 64 + lane) * 4;                             // offset of the aligned group
+        const bool inr = i < len + mis;
+        const unsigned col = (unsigned)(start - mis) + (unsigned)i;
+        lcol[u4] = inr ? col : OOB;
+        // panel images: [RS / 64][panel_rows][64] -- an aligned group of four samples is contiguous in either layout
+        lpan[u4] = inr ? (panel_rows > 0 ? (col >> 6) * (unsigned)panel_rows * 64u + (col & 63u) : col) : OOB;
+    }
+    const unsigned prs = panel_rows > 0 ? 64u : (unsigned)RS;           // row stride of the data image
+    auto issue = [&](const int row, Raw& r) {
+        // the row's offset is scalar (not part of the range check); a row past the image gets EMPTY descriptors
+        const bool rv = row < R;
+        const unsigned ro = rv ? (unsigned)row * (unsigned)RS : 0u, rp = rv ? (unsigned)row * prs : 0u;
+        const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)bd, 0, (int)(rv ? nd : 0u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsf = __builtin_amdgcn_make_buffer_rsrc((void*)bf, 0, (int)(rv ? nf : 0u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsf2 = __builtin_amdgcn_make_buffer_rsrc((void*)bf2, 0, (int)(rv ? nf2 : 0u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc((void*)bc, 0, (int)(rv ? nc : 0u), 0x00020000);
+#pragma unroll
+        for (int u4 = 0; u4 < NG; u4++) {
+            r.d[u4] = __builtin_amdgcn_raw_buffer_load_b128(rsd, (int)(lpan[u4] < OOB ? lpan[u4] * 4u : OOB), (int)(rp * 4u), 0);
+            r.fa[u4] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsf, (int)lcol[u4], (int)ro, 0);
+            r.fb[u4] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsf2, (int)lpan[u4], (int)rp, 0);
+            r.fc[u4] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsc, (int)lcol[u4], 0, 0);
+        }
+    };
+    Raw cur;
+    if (VEC4) issue(row0, cur);
+#pragma unroll 1
+    for (int js = 0; js < SPW; js++) {
+    const int row = row0 + js;
+    if (row >= R) break;                                                // (wave-uniform)
+    Raw nxt;
+    if (VEC4 && SPW > 1) issue(js + 1 < SPW ? row + 1 : R, nxt);
     unsigned keys[KS];
     unsigned nloc = 0;
     if (VEC4) {
-        // rows are 16-byte aligned and a multiple of 4 long: float4 / uchar4 loads
-        // of the aligned groups covering the segment, samples outside it masked
-        // (a selection does not care which lane holds which sample)
-        const int mis = live ? (int)(seg_start[g] & 3) : 0;
-        const float* d4 = d - mis;
-        const uint8_t* f4 = f - mis;
 #pragma unroll
-        for (int u4 = 0; u4 < KS / 4; u4++) {
-            const int i = (u4 * 64 + lane) * 4;          // offset of the aligned group
-            float4 dv = make_float4(0.f, 0.f, 0.f, 0.f);
-            uchar4 fv = make_uchar4(1, 1, 1, 1);
-            if (i < len + mis) {
-                const float* dp = d4 + i;                    // the group in the data image / the second flag image
-                const uint8_t* f2p = f2 ? f2 - mis + i : nullptr;
-                if (panel_rows > 0) {
-                    const int col = (int)seg_start[g] - mis + i;
-                    const size_t pi = ((size_t)(col >> 6) * panel_rows + row) * 64 + (col & 63);
-                    dp = data + win * WSd + pi;
-                    if (f2) f2p = flags2 + win * WSf + pi;
-                }
-                dv = *reinterpret_cast<const float4*>(dp);
-                unsigned fw = *reinterpret_cast<const unsigned*>(f4 + i);
-                if (f2) fw |= *reinterpret_cast<const unsigned*>(f2p);
-                if (cf) fw |= *reinterpret_cast<const unsigned*>(cf - mis + i);
-                fv = make_uchar4((unsigned char)(fw & 0xFFu), (unsigned char)((fw >> 8) & 0xFFu), (unsigned char)((fw >> 16) & 0xFFu), (unsigned char)(fw >> 24));
-            }
-            const int j = i - mis;                         // logical index of the group's first sample
-            const bool v0 = j >= 0 && j < len && !fv.x;
-            const bool v1 = j + 1 >= 0 && j + 1 < len && !fv.y;
-            const bool v2 = j + 2 >= 0 && j + 2 < len && !fv.z;
-            const bool v3 = j + 3 >= 0 && j + 3 < len && !fv.w;
-            keys[4 * u4 + 0] = v0 ? (__float_as_uint(dv.x) & 0x7FFFFFFFu) : SENT;
-            keys[4 * u4 + 1] = v1 ? (__float_as_uint(dv.y) & 0x7FFFFFFFu) : SENT;
-            keys[4 * u4 + 2] = v2 ? (__float_as_uint(dv.z) & 0x7FFFFFFFu) : SENT;
-            keys[4 * u4 + 3] = v3 ? (__float_as_uint(dv.w) & 0x7FFFFFFFu) : SENT;
+        for (int u4 = 0; u4 < NG; u4++) {
+            const int i = (u4 * 64 + lane) * 4;
+            const u32x4 dv = cur.d[u4];
+            const unsigned fw = cur.fa[u4] | cur.fb[u4] | cur.fc[u4];
+            const int j = i - mis;                                      // logical index of the group's first sample
+            const bool v0 = j >= 0 && j < len && !(fw & 0xFFu);
+            const bool v1 = j + 1 >= 0 && j + 1 < len && !(fw & 0xFF00u);
+            const bool v2 = j + 2 >= 0 && j + 2 < len && !(fw & 0xFF0000u);
+            const bool v3 = j + 3 >= 0 && j + 3 < len && !(fw & 0xFF000000u);
+            keys[4 * u4 + 0] = v0 ? (dv.x & 0x7FFFFFFFu) : SENT;
+            keys[4 * u4 + 1] = v1 ? (dv.y & 0x7FFFFFFFu) : SENT;
+            keys[4 * u4 + 2] = v2 ? (dv.z & 0x7FFFFFFFu) : SENT;
+            keys[4 * u4 + 3] = v3 ? (dv.w & 0x7FFFFFFFu) : SENT;
             nloc += (v0 ? 1 : 0) + (v1 ? 1 : 0) + (v2 ? 1 : 0) + (v3 ? 1 : 0);
         }
     } else {
+        const size_t rel = (size_t)row * RS + (size_t)seg_start[g] * ES;
+        const float* d = data + win * WSd + rel;
+        const uint8_t* f = flags + win * WSf + rel;
+        const uint8_t* f2 = flags2 ? flags2 + win * WSf + rel : nullptr;
+        const uint8_t* cf = colflags ? colflags + win * WScol + (size_t)seg_start[g] : nullptr;
 #pragma unroll
         for (int u = 0; u < KS; u++) {
             int i = u * 64 + lane;
@@ -1015,6 +1067,16 @@ k_median_wave(const float* __restrict__ data, const uint8_t* __restrict__ flags,
         }
     }
     const unsigned n = wave_sum_u32(nloc);
+#if defined(MEDW_ABLATE)                                                 // (harness only) loads + key building
+    {
+        unsigned acc = 0;
+#pragma unroll
+        for (int u = 0; u < KS; u++) acc ^= keys[u];
+        if (acc == 0x12345u) med[(win * (size_t)R + row) * G + g] = (double)n;
+        if (VEC4 && SPW > 1) cur = nxt;
+        continue;
+    }
+#endif
     // Normalise the keys to their minimum and radix-select only the B
     // significant bits of the spread: the leading digit then follows the
     // sample distribution (a plain top byte of a float is its exponent, which
@@ -1035,7 +1097,7 @@ k_median_wave(const float* __restrict__ data, const uint8_t* __restrict__ flags,
     bool single = false;
     unsigned* h = hist[wave];
     // Each wave owns its histogram and LDS operations of one wave execute in
-    // order, so the passes need no workgroup barrier (the four segments of a
+    // order, so the passes need no workgroup barrier (the four waves of a
     // workgroup differ in sample count and digit count): a wave-level fence
     // keeps the compiler from reordering around the atomics.
     auto wave_sync = [] {
@@ -1056,12 +1118,7 @@ k_median_wave(const float* __restrict__ data, const uint8_t* __restrict__ flags,
         {
             uint4 hv = reinterpret_cast<uint4*>(h)[lane];
             unsigned sacc = hv.x + hv.y + hv.z + hv.w;
-            unsigned inc = sacc;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                unsigned v = __shfl_up(inc, o, 64);
-                if (lane >= o) inc += v;
-            }
+            const unsigned inc = wave_scan_u32(sacc);
             unsigned exc = inc - sacc;
             bool mine = n > 0 && kk >= exc && kk < inc;
             unsigned dsel = 0, cbase = exc, csel = hv.x;
@@ -1073,12 +1130,12 @@ k_median_wave(const float* __restrict__ data, const uint8_t* __restrict__ flags,
             }
             unsigned long long bm = __ballot(mine);
             if (bm) {
-                int src = __ffsll((long long)bm) - 1;
-                unsigned digit = __shfl(4u * lane + dsel, src, 64);
-                unsigned base = __shfl(cbase, src, 64);
+                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)bm) - 1);      // (scalar: v_readlane, no LDS trip)
+                const unsigned digit = 4u * (unsigned)src + (unsigned)__builtin_amdgcn_readlane((int)dsel, src);
+                const unsigned base = (unsigned)__builtin_amdgcn_readlane((int)cbase, src);
                 prefix |= digit << shift;   // overlapping bits of a short last digit are already equal
                 kk -= base;
-                single = __shfl(csel, src, 64) == 1u;
+                single = (unsigned)__builtin_amdgcn_readlane((int)csel, src) == 1u;
             }
             pmask |= 0xFFu << shift;
         }
@@ -1109,7 +1166,7 @@ k_median_wave(const float* __restrict__ data, const uint8_t* __restrict__ flags,
         mx = wave_max_u32(mx) + kmin;
     }
     const unsigned hi = prefix + kmin;
-    if (live && lane == 0) {
+    if (lane == 0) {
         size_t oidx = (win * (size_t)R + row) * G + g;
         double m;
         if (n == 0) m = __longlong_as_double(0x7FF8000000000000LL);
@@ -1120,6 +1177,8 @@ k_median_wave(const float* __restrict__ data, const uint8_t* __restrict__ flags,
             m = (double)sm / 2.0;
         }
         med[oidx] = m;
+    }
+    if (VEC4 && SPW > 1) cur = nxt;
     }
 }
 

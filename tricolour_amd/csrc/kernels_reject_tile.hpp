@@ -189,7 +189,10 @@ k_mr_predict(const float* __restrict__ resid, const uint8_t* __restrict__ flags_
 
 // ---- the pass: one workgroup per chunk-aligned tile of 64 rows x 64 words -----------------------------------------------
 // grid (ceil(C4 / 64), sum over chunks of ceil(rows / 64), W), block 256
-__global__ void __launch_bounds__(256)
+#ifndef MRT_PASS_WAVES
+#define MRT_PASS_WAVES 4                 // waves per SIMD the pass is compiled for (HIP: second __launch_bounds__ argument)
+#endif
+__global__ void __launch_bounds__(256, MRT_PASS_WAVES)
 k_mr_pass(const float* __restrict__ resid, const uint8_t* __restrict__ flags_in, uint8_t* __restrict__ flags_out,
           uint8_t* __restrict__ flags_t4, const int64_t* __restrict__ chunk_ends, int L, int C4, int G,
           size_t ws_resid, size_t ws_flags, unsigned* __restrict__ gscratch, size_t scratch_ws, size_t ccap, size_t ucap, unsigned round) {

@@ -430,17 +430,35 @@ int launch_median(const Run& r, const float* data, const uint8_t* flags, double*
     const bool row4 = ES == 1 && RS % 4 == 0 && WSd % 4 == 0 && WSf % 4 == 0 &&
                       ((uintptr_t)data % 16 == 0) && ((uintptr_t)flags % 4 == 0) && rows_aligned;
     const int64_t slack = segs_aligned ? 0 : 3;   // misaligned segment starts cost up to 3 masked slots
+    // wave medians: MW_SPW rows of a segment per wave, the next row's loads in flight (round 4; TRI_MEDIAN_WAVE_OLD=1: one segment per wave)
+    static const bool wave_old = [] { const char* e = getenv("TRI_MEDIAN_WAVE_OLD"); return e && e[0] == '1'; }();
+    if (max_len <= 64 * MW_K && !wave_old) {
+        if (max_len + slack <= 64 * 8 && row4)
+            hipLaunchKernelGGL((k_median_wave<8, true, MW_SPW>), dim3((unsigned)cdiv((int64_t)cdiv((int64_t)R, MW_SPW) * G, 4), (unsigned)W), dim3(256), 0, r.st,
+                               data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G, flags2, colflags, WScol, panel_rows);
+        else if (max_len <= 64 * 8 && panel_rows == 0)               // (panel images: the 16-byte kernels only)
+            hipLaunchKernelGGL((k_median_wave<8, false, MW_SPW>), dim3((unsigned)cdiv((int64_t)cdiv((int64_t)R, MW_SPW) * G, 4), (unsigned)W), dim3(256), 0, r.st,
+                               data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G, flags2, colflags, WScol);
+        else if (max_len + slack <= 64 * MW_K && row4)
+            hipLaunchKernelGGL((k_median_wave<MW_K, true, MW_SPW16>), dim3((unsigned)cdiv((int64_t)cdiv((int64_t)R, MW_SPW16) * G, 4), (unsigned)W), dim3(256), 0, r.st,
+                               data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G, flags2, colflags, WScol, panel_rows);
+        else if (max_len <= 64 * MW_K)
+            hipLaunchKernelGGL((k_median_wave<MW_K, false, MW_SPW16>), dim3((unsigned)cdiv((int64_t)cdiv((int64_t)R, MW_SPW16) * G, 4), (unsigned)W), dim3(256), 0, r.st,
+                               data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G, flags2, colflags, WScol);
+        LAUNCHCHK();
+        return TRI_OK;
+    }
     if (max_len + slack <= 64 * 8 && row4)
-        hipLaunchKernelGGL((k_median_wave<8, true>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)W), dim3(256), 0, r.st,
+        hipLaunchKernelGGL((k_median_wave<8, true, 1>), dim3((unsigned)cdiv((int64_t)cdiv((int64_t)R, 1) * G, 4), (unsigned)W), dim3(256), 0, r.st,
                            data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G, flags2, colflags, WScol, panel_rows);
     else if (max_len <= 64 * 8 && panel_rows == 0)               // (panel images: the 16-byte kernels only)
-        hipLaunchKernelGGL((k_median_wave<8, false>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)W), dim3(256), 0, r.st,
+        hipLaunchKernelGGL((k_median_wave<8, false, 1>), dim3((unsigned)cdiv((int64_t)cdiv((int64_t)R, 1) * G, 4), (unsigned)W), dim3(256), 0, r.st,
                            data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G, flags2, colflags, WScol);
     else if (max_len + slack <= 64 * MW_K && row4)
-        hipLaunchKernelGGL((k_median_wave<MW_K, true>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)W), dim3(256), 0, r.st,
+        hipLaunchKernelGGL((k_median_wave<MW_K, true, 1>), dim3((unsigned)cdiv((int64_t)cdiv((int64_t)R, 1) * G, 4), (unsigned)W), dim3(256), 0, r.st,
                            data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G, flags2, colflags, WScol, panel_rows);
     else if (max_len <= 64 * MW_K)
-        hipLaunchKernelGGL((k_median_wave<MW_K, false>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)W), dim3(256), 0, r.st,
+        hipLaunchKernelGGL((k_median_wave<MW_K, false, 1>), dim3((unsigned)cdiv((int64_t)cdiv((int64_t)R, 1) * G, 4), (unsigned)W), dim3(256), 0, r.st,
                            data, flags, med, WSd, WSf, RS, ES, seg_start, seg_len, R, G, flags2, colflags, WScol);
     else {
         // long segments: two-pass select (K3c); TRI_MEDIAN_3PASS=1 keeps the three-pass kernel (A/B runs, tests)
@@ -2468,21 +2486,37 @@ extern "C" int tri_test_median(const float* data, const uint8_t* flags, double* 
         return rcb;
     }
     if (variant == 0) variant = maxlen <= 64 * MW_K ? 1 : (al4 ? 3 : 2);
+    // variants 11 / 14: variants 1 / 4 with one segment per wave (the round-3 launch shape; TRI_MEDIAN_WAVE_OLD=1 in the pipeline)
+    const bool wave_old = variant == 11 || variant == 14;
+    if (wave_old) variant -= 10;
     if ((variant == 1 || variant == 4) && maxlen > 64 * MW_K) return set_err(TRI_EINVAL, "wave kernel handles segments <= 1024");
     if (variant == 4 && (row_len % 4 != 0 || maxlen + 3 > 64 * MW_K)) return set_err(TRI_EINVAL, "masked vector variant needs row_len % 4 == 0 and segments <= 1021");
     if ((variant == 3 || variant == 5) && !al4) return set_err(TRI_EINVAL, "vector loads need 4-aligned segments");
-    if (variant == 1 && maxlen <= 64 * 8)
-        hipLaunchKernelGGL((k_median_wave<8, false>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)n_win), dim3(256), 0, st,
+    if (wave_old && variant == 1 && maxlen <= 64 * 8)
+        hipLaunchKernelGGL((k_median_wave<8, false, 1>), dim3((unsigned)cdiv((int64_t)cdiv((int64_t)R, 1) * G, 4), (unsigned)n_win), dim3(256), 0, st,
+                           data, flags, med, WS, WS, RS, (size_t)1, d_start, d_len, R, G);
+    else if (wave_old && variant == 4 && row_len % 4 == 0 && maxlen + 3 <= 64 * 8)
+        hipLaunchKernelGGL((k_median_wave<8, true, 1>), dim3((unsigned)cdiv((int64_t)cdiv((int64_t)R, 1) * G, 4), (unsigned)n_win), dim3(256), 0, st,
+                           data, flags, med, WS, WS, RS, (size_t)1, d_start, d_len, R, G);
+    else if (wave_old && ((variant == 4 && row_len % 4 == 0 && maxlen + 3 <= 64 * MW_K) ||
+             (variant == 1 && G == 1 && al4 && seg_ends[0] == 0 && seg_ends[1] == row_len)))
+        hipLaunchKernelGGL((k_median_wave<MW_K, true, 1>), dim3((unsigned)cdiv((int64_t)cdiv((int64_t)R, 1) * G, 4), (unsigned)n_win), dim3(256), 0, st,
+                           data, flags, med, WS, WS, RS, (size_t)1, d_start, d_len, R, G);
+    else if (wave_old && variant == 1)
+        hipLaunchKernelGGL((k_median_wave<MW_K, false, 1>), dim3((unsigned)cdiv((int64_t)cdiv((int64_t)R, 1) * G, 4), (unsigned)n_win), dim3(256), 0, st,
+                           data, flags, med, WS, WS, RS, (size_t)1, d_start, d_len, R, G);
+    else if (variant == 1 && maxlen <= 64 * 8)
+        hipLaunchKernelGGL((k_median_wave<8, false, MW_SPW>), dim3((unsigned)cdiv((int64_t)cdiv((int64_t)R, MW_SPW) * G, 4), (unsigned)n_win), dim3(256), 0, st,
                            data, flags, med, WS, WS, RS, (size_t)1, d_start, d_len, R, G);
     else if (variant == 4 && row_len % 4 == 0 && maxlen + 3 <= 64 * 8)
-        hipLaunchKernelGGL((k_median_wave<8, true>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)n_win), dim3(256), 0, st,
+        hipLaunchKernelGGL((k_median_wave<8, true, MW_SPW>), dim3((unsigned)cdiv((int64_t)cdiv((int64_t)R, MW_SPW) * G, 4), (unsigned)n_win), dim3(256), 0, st,
                            data, flags, med, WS, WS, RS, (size_t)1, d_start, d_len, R, G);
     else if ((variant == 4 && row_len % 4 == 0 && maxlen + 3 <= 64 * MW_K) ||
              (variant == 1 && G == 1 && al4 && seg_ends[0] == 0 && seg_ends[1] == row_len))
-        hipLaunchKernelGGL((k_median_wave<MW_K, true>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)n_win), dim3(256), 0, st,
+        hipLaunchKernelGGL((k_median_wave<MW_K, true, MW_SPW16>), dim3((unsigned)cdiv((int64_t)cdiv((int64_t)R, MW_SPW16) * G, 4), (unsigned)n_win), dim3(256), 0, st,
                            data, flags, med, WS, WS, RS, (size_t)1, d_start, d_len, R, G);
     else if (variant == 1)
-        hipLaunchKernelGGL((k_median_wave<MW_K, false>), dim3((unsigned)cdiv((int64_t)R * G, 4), (unsigned)n_win), dim3(256), 0, st,
+        hipLaunchKernelGGL((k_median_wave<MW_K, false, MW_SPW16>), dim3((unsigned)cdiv((int64_t)cdiv((int64_t)R, MW_SPW16) * G, 4), (unsigned)n_win), dim3(256), 0, st,
                            data, flags, med, WS, WS, RS, (size_t)1, d_start, d_len, R, G);
     else if (variant == 3)
         hipLaunchKernelGGL(k_median<true>, dim3((unsigned)(R * G), (unsigned)n_win), dim3(256), 0, st, data, flags,
