@@ -290,6 +290,49 @@ def roofline_sumthreshold(torch, device, T, F, kw, nwin):
                 ms_per_launch=round(ms.value, 4))
 
 
+def roofline_reject(torch, device, T, F, kw, nwin):
+    """Times one rejection step of the background loop (block median of |data - background| + threshold comparison,
+    flagging.py:553-574) in the step's geometry: all `nwin` windows, `freq_chunks` blocks per window, through the library's
+    measurement hook (k_mr_predict, two rounds of k_mr_pass + k_mr_finish, the redo kernel).  7 B per sample in the pass
+    (4 B residual + 1 B flag read, 1 B flag + 1 B transposed flag written) + the lists and patches of the other kernels."""
+    from tricolour_amd import _lib
+    lib = _lib.lib()
+    g = torch.Generator(device=device)
+    g.manual_seed(11)
+    resid = torch.randn((nwin, F, T), generator=g, device=device).abs_()
+    fin = (torch.rand((nwin, F, T), generator=g, device=device) < 0.05).view(torch.uint8)
+    fout = torch.empty((nwin, F, T), dtype=torch.uint8, device=device)
+    ft4 = torch.empty((nwin, T // 4, F, 4), dtype=torch.uint8, device=device)
+    nchunk = int(kw.get("freq_chunks", 10))
+    ends = [int(x) for x in np.linspace(0, F, nchunk + 1)]      # (flagging.py:936: np.linspace(0, nfreq, freq_chunks + 1, dtype=int))
+    med = torch.empty((nwin, nchunk), dtype=torch.float64, device=device)
+    earr = (C.c_int64 * len(ends))(*ends)
+    ms = C.c_float(0)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    names = {}
+    for reps in (2, 6):
+        _lib.kernel_log_begin()
+        rc = lib.tri_bench_reject(resid.data_ptr(), fin.data_ptr(), fout.data_ptr(), ft4.data_ptr(), med.data_ptr(), nwin, F, T,
+                                  earr, len(ends), float(kw.get("background_reject", 2.0)), reps, C.byref(ms), stream)
+        names = _lib.kernel_log_end()
+        if rc == _lib.TRI_EUNSUPPORTED:
+            return None
+        _lib.check(rc)
+    samples = nwin * T * F
+    bps = 7
+    achieved = samples * bps / (ms.value * 1e-3) / 1e9
+    devk = sorted(names)
+    per_meas = sum(names.values()) // 6 if names else 1
+    traffic, src = _pmc_traffic("reject", samples, devk)
+    return dict(bound="hbm", kernel="rejection step of the background loop (block median + threshold in one pass): " + ", ".join(devk),
+                device_kernels=devk, launches_per_measurement=max(per_meas, 1),
+                timed="the whole step (six launches) through the library's measurement hook tri_bench_reject, in the step's launch geometry, "
+                      "HIP events on the launch stream",
+                achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
+                traffic=traffic, traffic_source=src, algorithmic_bytes_per_launch=samples * bps, bytes_per_sample=bps,
+                samples_per_launch=samples, ms_per_launch=round(ms.value, 4))
+
+
 def roofline_boxfilter(torch, device, T, F, kw, nwin):
     """Times the two stages of one masked box filter (flagging.py:469-513) in the step's launch geometry at the
     radii of the parameter set: the time-axis stage at its largest radius (first background iteration) and the
@@ -726,8 +769,9 @@ def main():
 
     if args.roofline_only:
         nwin = min(nbl * ncorr, 1008 if wl != "ska" else 64)
-        print(json.dumps({"roofline_kernels": [roofline_sumthreshold(torch, device, T, F, kw, nwin)] +
-                          roofline_boxfilter(torch, device, T, F, kw, nwin), "lib_sha16": _lib.source_hash()}))
+        rk = [roofline_sumthreshold(torch, device, T, F, kw, nwin)] + roofline_boxfilter(torch, device, T, F, kw, nwin)
+        rj = roofline_reject(torch, device, T, F, kw, nwin)
+        print(json.dumps({"roofline_kernels": rk + ([rj] if rj else []), "lib_sha16": _lib.source_hash()}))
         return
 
     extra = {}
@@ -844,6 +888,9 @@ def main():
         if not args.no_roofline:
             kernels = [roofline_sumthreshold(torch, device, T, F, kw, nwin)] + \
                 roofline_boxfilter(torch, device, T, F, kw, nwin)
+            rj = roofline_reject(torch, device, T, F, kw, nwin)
+            if rj:
+                kernels.append(rj)
             # "roofline" = ONE object: the kernel with the largest share of the timed step -- the box-filter
             # stage that runs at the most radii of the parameter set (the fused frequency-axis stage at its
             # largest radius when there are several background iterations, else the time-axis stage);

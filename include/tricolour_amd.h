@@ -350,6 +350,25 @@ int tri_sum_threshold_flagger_debug(const void *vis, int vis_dtype,
                                     void *stream, float *dbg_f32, uint8_t *dbg_u8);
 
 /*
+ * Measurement / test hook: ONE rejection step of the background loop,
+ *     flags |= resid > median_abs(resid[~flags]) * 1.4826 * reject     per (window, chunk) block
+ * (flagging.py:553-574 with _median_abs :267), by the one-pass route the flagger
+ * takes for blocks of at least 65536 samples (k_mr_predict / k_mr_pass /
+ * k_mr_finish + the redo kernel; TRI_EUNSUPPORTED for smaller blocks).
+ * resid (n_win, n_chan, n_time) float32 and flags_in (same shape, bytes) are the
+ * channel-major images of the loop; flags_out (same shape) receives the new
+ * flags, flags_t4 (n_win, n_time / 4, n_chan, 4) the same flags with four
+ * consecutive times of a channel per 32-bit word (the time-axis filter's input),
+ * med (n_win, n_chunk_ends - 1) float64 the block medians (NaN: nothing
+ * unflagged).  chunk_ends is a HOST array of channel boundaries, 0 ... n_chan.
+ * ms_per_step: mean time of the whole step over `repeats`, HIP events on `stream`.
+ */
+int tri_bench_reject(const float *resid, const uint8_t *flags_in, uint8_t *flags_out,
+                     uint8_t *flags_t4, double *med, int64_t n_win, int64_t n_chan,
+                     int64_t n_time, const int64_t *chunk_ends, int64_t n_chunk_ends,
+                     double reject, int repeats, float *ms_per_step, void *stream);
+
+/*
  * Test hook: exact segmented medians of |x| over the unflagged samples of a
  * (n_win, rows, row_len) float32 array; segments [seg_ends[g], seg_ends[g+1])
  * (HOST array) along each row; med is (n_win, rows, n_seg_ends - 1) float64,

@@ -635,6 +635,58 @@ def test_median_wave_corners(gpu, row_len, ends):
         assert np.array_equal(got, exp), "variant %d: %d medians differ" % (variant, (got != exp).sum())
 
 
+@pytest.mark.parametrize("n_win,F,T,ends,reject", [
+    (2, 256, 1024, [0, 128, 256], 2.0),
+    (3, 200, 1024, [0, 67, 131, 200], 1.5),        # chunks that are not multiples of the 64-row tiles
+    (1, 512, 512, [0, 512], 3.0),
+])
+def test_rejection_step_hook_vs_numpy(gpu, n_win, F, T, ends, reject):
+    """tri_bench_reject = one rejection step of the background loop by the one-pass route (k_mr_predict / k_mr_pass /
+    k_mr_finish + redo): flags |= resid > median_abs(resid[~flags]) * 1.4826 * reject per (window, chunk) block
+    (flagging.py:553-574), the flags also as TF4 words, the block medians -- against numpy, with duplicate-heavy, constant,
+    all-flagged and wide-range blocks among the ordinary ones."""
+    import ctypes as C
+    import torch
+    from tricolour_amd import _lib
+    rs = np.random.RandomState(n_win * 100 + F)
+    resid = np.abs(rs.standard_normal((n_win, F, T))).astype(np.float32)
+    resid[0, : ends[1], ::7] = np.float32(0.25)                       # duplicates around the median
+    resid[-1, ends[-2]:, :] *= np.float32(1e-12)
+    resid[-1, ends[-2]:, ::5] *= np.float32(1e20)                      # 32 decimal orders inside one block
+    flags = rs.uniform(size=resid.shape) < 0.1
+    if n_win > 1:
+        flags[1, : ends[1]] = True                                     # nothing unflagged in a block
+        resid[1, ends[1]: ends[2]] = np.float32(3.0)                   # a constant block
+    resid[0, 5, 5] = np.nan
+    G = len(ends) - 1
+    exp_med = np.empty((n_win, G))
+    exp = flags.copy()
+    for w in range(n_win):
+        for g in range(G):
+            blk = (w, slice(ends[g], ends[g + 1]))
+            m = _np_median_abs(resid[blk][~flags[blk]])
+            exp_med[w, g] = m
+            with np.errstate(invalid="ignore"):
+                exp[blk] |= resid[blk].astype(np.float64) > m * (1.4826 * reject)
+    d = torch.from_numpy(resid).cuda()
+    f = torch.from_numpy(flags).cuda().view(torch.uint8)
+    fo = torch.full((n_win, F, T), 0xEE, dtype=torch.uint8, device="cuda")
+    t4 = torch.full((n_win, T // 4, F, 4), 0xDD, dtype=torch.uint8, device="cuda")
+    med = torch.full((n_win, G), -1.0, dtype=torch.float64, device="cuda")
+    e = (C.c_int64 * len(ends))(*ends)
+    ms = C.c_float(0)
+    _lib.check(_lib.lib().tri_bench_reject(d.data_ptr(), f.data_ptr(), fo.data_ptr(), t4.data_ptr(), med.data_ptr(), n_win, F, T,
+                                           e, len(ends), reject, 1, C.byref(ms), None))
+    got_med = med.cpu().numpy()
+    assert ((got_med == exp_med) | (np.isnan(got_med) & np.isnan(exp_med))).all(), (got_med, exp_med)
+    got = fo.cpu().numpy()
+    assert np.array_equal(got != 0, exp), "%d FT flags differ" % ((got != 0) != exp).sum()
+    assert set(np.unique(got)) <= {0, 1}
+    got4 = t4.cpu().numpy().transpose(0, 2, 1, 3).reshape(n_win, F, T)
+    assert np.array_equal(got4, got), "%d TF4 flag bytes differ from the FT image" % (got4 != got).sum()
+    assert ms.value > 0
+
+
 EDGE_CASES = [
     # (shape, kwargs)
     ((1, 1, 1, 16), dict(num_major_iterations=1)),

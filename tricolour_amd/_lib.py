@@ -157,6 +157,9 @@ _SIGNATURES = {
     "tri_bench_boxfilter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                       C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(C.c_float), C.c_void_p]),
+    "tri_bench_reject": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                   C.c_int64, C.POINTER(C.c_int64), C.c_int64, C.c_double, C.c_int,
+                                   C.POINTER(C.c_float), C.c_void_p]),
     "tri_boxx_last_stats": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "tri_kernel_log": (C.c_int, [C.c_int, C.c_char_p, C.c_int64]),
     "tri_medrej_stats": (C.c_int, [C.POINTER(C.c_uint64), C.c_int]),

@@ -2139,6 +2139,68 @@ extern "C" int tri_unpack_data(const uint8_t* flag_windows, const int32_t* row_b
     return TRI_OK;
 }
 
+// Measurement / test hook: ONE rejection step of the background loop (flagging.py:553-574) as the flagger runs it for blocks
+// of >= 65536 samples: k_mr_predict, two rounds of k_mr_pass + k_mr_finish, the redo kernel (K3t).  resid: (n_win, n_chan, n_time)
+// float32 = |data - background| in the FT layout, flags_in: (n_win, n_chan, n_time) bytes; flags_out (FT bytes), flags_t4 (TF4 words,
+// (n_win, n_time / 4, n_chan) x 4 bytes) and med (n_win, n_chunks) float64 receive the results.
+extern "C" int tri_bench_reject(const float* resid, const uint8_t* flags_in, uint8_t* flags_out, uint8_t* flags_t4, double* med,
+                                int64_t n_win, int64_t n_chan, int64_t n_time, const int64_t* chunk_ends, int64_t n_chunk_ends,
+                                double reject, int repeats, float* ms_per_step, void* stream) {
+    if (!resid || !flags_in || !flags_out || !flags_t4 || !med || !chunk_ends || !ms_per_step) return set_err(TRI_EINVAL, "NULL pointer argument");
+    if (n_win <= 0 || n_win > 65535 || n_chan <= 0 || n_time <= 0 || n_time % 4 != 0 || n_chunk_ends < 2 || n_chunk_ends > 256 || repeats <= 0)
+        return set_err(TRI_EINVAL, "bad shape");
+    if ((uint64_t)n_chan * (uint64_t)n_time * 4u >= (1ull << 31)) return set_err(TRI_EUNSUPPORTED, "a window of 2^31 bytes or more");
+    const int G = (int)n_chunk_ends - 1, T = (int)n_time, Fa = (int)n_chan;
+    int64_t maxchunk = 0, minchunk = n_chan;
+    int ytiles = 0;
+    for (int g = 0; g < G; g++) {
+        const int64_t c = chunk_ends[g + 1] - chunk_ends[g];
+        if (c <= 0 || chunk_ends[g] < 0 || chunk_ends[g + 1] > n_chan) return set_err(TRI_EINVAL, "bad chunk");
+        maxchunk = std::max(maxchunk, c); minchunk = std::min(minchunk, c);
+        ytiles += (int)cdiv(c, 64);
+    }
+    if (chunk_ends[0] != 0 || chunk_ends[G] != n_chan) return set_err(TRI_EINVAL, "chunks must cover the channels");
+    if (minchunk * (int64_t)T < 65536 || ytiles > 65535) return set_err(TRI_EUNSUPPORTED, "blocks below 65536 samples take the two-kernel route");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t N = (size_t)Fa * T;
+    const size_t nb = (size_t)maxchunk * T, ccap = (nb / 4) & ~(size_t)3, ucap = (nb / 8) & ~(size_t)3;
+    const size_t wsS = mrt_scratch_words(G, ccap, ucap);
+    unsigned* sc = nullptr;
+    int64_t* d_ends = nullptr;
+    HIPCHK(hipMalloc(&sc, (size_t)n_win * wsS * sizeof(unsigned)));
+    HIPCHK(hipMalloc(&d_ends, (size_t)n_chunk_ends * sizeof(int64_t)));
+    HIPCHK(hipMemcpyAsync(d_ends, chunk_ends, (size_t)n_chunk_ends * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const double rej = TRI_MAD_NORMAL * reject;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    const unsigned W = (unsigned)n_win;
+    HIPCHK(hipEventRecord(e0, st));
+    for (int i = 0; i < repeats; i++) {
+        hipLaunchKernelGGL(k_mr_predict, dim3((unsigned)G, W), dim3(256), 0, st, resid, flags_in, d_ends, rej, T / 4, G, N, N, sc, wsS, ccap, ucap, 0);
+        for (unsigned round = 1; round <= 2; round++) {
+            hipLaunchKernelGGL(k_mr_pass, dim3((unsigned)cdiv(T / 4, 64), (unsigned)ytiles, W), dim3(256), 0, st, resid, flags_in, flags_out, flags_t4,
+                               d_ends, Fa, T / 4, G, N, N, sc, wsS, ccap, ucap, round);
+            hipLaunchKernelGGL(k_mr_finish, dim3((unsigned)G, W), dim3(256), 0, st, resid, flags_in, flags_out, flags_t4, med, d_ends, rej, Fa, T / 4, G,
+                               N, N, sc, wsS, ccap, ucap, round);
+        }
+        hipLaunchKernelGGL(k_median_reject, dim3((unsigned)G, W), dim3(256), 0, st, resid, flags_in, flags_out, flags_t4, med, d_ends, rej, Fa, T / 4, G,
+                           N, N, sc, wsS, 0u, 0u, 1, (const unsigned*)sc, wsS, (int)MRT_PARW, 11);
+    }
+    HIPCHK(hipEventRecord(e1, st));
+    hipError_t le = hipGetLastError();
+    hipError_t se = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (le == hipSuccess && se == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(sc); (void)hipFree(d_ends);
+    if (le != hipSuccess) return set_err(TRI_EHIP, "launch: %s", hipGetErrorString(le));
+    if (se != hipSuccess) return set_err(TRI_EHIP, "sync: %s", hipGetErrorString(se));
+    *ms_per_step = ms / (float)repeats;
+    return TRI_OK;
+}
+
 extern "C" int tri_bench_sumthreshold(const float* data, const double* mad, uint8_t* out,
                                       int64_t n_win, int64_t n_line, int64_t n_col,
                                       const int64_t* windows, int64_t n_windows,
