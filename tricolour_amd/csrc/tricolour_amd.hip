@@ -427,8 +427,11 @@ int launch_median(const Run& r, const float* data, const uint8_t* flags, double*
     if ((int64_t)R * G > 0x7FFFFFFF || W > 65535) return set_err(TRI_EUNSUPPORTED, "median grid too large");
     // segments of contiguous 4-aligned rows can be loaded 16 bytes at a time
     // (misaligned segment ends are masked, costing up to 3 extra slots)
+    // (the 16-byte wave kernels address a window's image through 32-bit buffer offsets: below 4 GB)
     const bool row4 = ES == 1 && RS % 4 == 0 && WSd % 4 == 0 && WSf % 4 == 0 &&
-                      ((uintptr_t)data % 16 == 0) && ((uintptr_t)flags % 4 == 0) && rows_aligned;
+                      ((uintptr_t)data % 16 == 0) && ((uintptr_t)flags % 4 == 0) && rows_aligned &&
+                      (uint64_t)RS * (uint64_t)std::max(R, panel_rows) * 4u < (1ull << 32);
+    if (panel_rows > 0 && !row4) return set_err(TRI_EUNSUPPORTED, "panel images of 4 GB or more per window");
     const int64_t slack = segs_aligned ? 0 : 3;   // misaligned segment starts cost up to 3 masked slots
     // wave medians: MW_SPW rows of a segment per wave, the next row's loads in flight (round 4; TRI_MEDIAN_WAVE_OLD=1: one segment per wave)
     static const bool wave_old = [] { const char* e = getenv("TRI_MEDIAN_WAVE_OLD"); return e && e[0] == '1'; }();
@@ -2553,6 +2556,7 @@ extern "C" int tri_test_median(const float* data, const uint8_t* flags, double* 
     if (wave_old) variant -= 10;
     if ((variant == 1 || variant == 4) && maxlen > 64 * MW_K) return set_err(TRI_EINVAL, "wave kernel handles segments <= 1024");
     if (variant == 4 && (row_len % 4 != 0 || maxlen + 3 > 64 * MW_K)) return set_err(TRI_EINVAL, "masked vector variant needs row_len % 4 == 0 and segments <= 1021");
+    if ((uint64_t)rows * (uint64_t)row_len * 4u >= (1ull << 32) && (variant == 4 || variant == 1)) return set_err(TRI_EUNSUPPORTED, "wave kernels: a window below 4 GB");
     if ((variant == 3 || variant == 5) && !al4) return set_err(TRI_EINVAL, "vector loads need 4-aligned segments");
     if (wave_old && variant == 1 && maxlen <= 64 * 8)
         hipLaunchKernelGGL((k_median_wave<8, false, 1>), dim3((unsigned)cdiv((int64_t)cdiv((int64_t)R, 1) * G, 4), (unsigned)n_win), dim3(256), 0, st,
