@@ -111,7 +111,7 @@ int main(int argc, char** argv) {
         for (int w = 0; w < W; w++) {
             CK(hipMemcpy(par.data(), scratch + (size_t)w * wsS, par.size() * 4, hipMemcpyDeviceToHost));
             for (int g = 0; g < G; g++) { if (par[g * MRT_PARW + 11] == 0) { why[par[g * MRT_PARW + 13] & 15]++; const unsigned* q = &par[g * MRT_PARW];
-                printf("  redo w %d g %d: lo %08x S %u wlo %u whi %u ncand %u nund %u below1 %08x rounds %u why %u\n", w, g, q[0], q[1], q[2], q[3], q[8], q[9], q[10], q[12], q[13]); } redo += par[g * MRT_PARW + 11] == 0; brk += par[g * MRT_PARW + 12]; nc += par[g * MRT_PARW + 8]; nu += par[g * MRT_PARW + 9]; }
+                printf("  redo w %d g %d: lo %08x S %u wlo %u whi %u ncand %u nund %u below1 %08x rounds %u why %u\n", w, g, q[0], q[1], q[2], q[3], q[8], q[9], q[10], q[12], q[13]); } redo += par[g * MRT_PARW + 11] == 0; brk += par[g * MRT_PARW + 12] & 0xFFFFu; nc += par[g * MRT_PARW + 8]; nu += par[g * MRT_PARW + 9]; }
         }
         printf("tile form: FT flags differing %zu, TF4 %zu, medians %zu; blocks redone by one workgroup %zu, second rounds %zu of %d, window keys %.2f %%, undecided %.2f %% of the samples\n",
                bf, bt, bm, redo, brk, W * G, 100.0 * nc / (W * (double)N), 100.0 * nu / (W * (double)N));

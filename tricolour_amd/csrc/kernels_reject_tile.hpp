@@ -16,7 +16,8 @@
 //                                   lists with one reservation per wave and tile; decided flags to the FT image and, transposed,
 //                                   to the TF4 image
 //   k_mr_finish   (G, W)            per block: median's bin from the histogram, exact select over the window keys, bracket
-//                                   verification, the undecided samples against the exact threshold (byte stores)
+//                                   verification, the undecided samples against the exact threshold -- the pass decided them by a
+//                                   PROVISIONAL threshold (the middle of the predicted bin), so only those between the two are rewritten
 //   k_mr_pass / k_mr_finish again   ROUND 2 for the blocks whose median fell outside the window or the decision bracket: the
 //                                   histogram is complete, so the bin of the median is now KNOWN -- the window becomes that bin
 //                                   +- 1 and the same two kernels run once more over those blocks' tiles only (all other
@@ -40,11 +41,13 @@
 #define MRT_WUND 192                     // undecided samples (index, value) per wave and tile (~1.5 % expected)
 #endif
 #define MRT_PARW 16                      // words of a block's parameter record
+#define MRT_ANY_ROUND2 0x10000u           // in pad[0] of a window's FIRST record: some block of the window goes into a second round
 struct MrtPar {                          // (global memory, one per block; written by k_mr_predict, counters by k_mr_pass)
     unsigned lo, S, wlo, whi;            // histogram map, candidate window (bins)
     double thrA, thrB;                   // decision bracket
     unsigned ncand, nund, below1, status;   // list fill, largest key below the window + 1, 1 = predicted / 0 = redo the block
-    unsigned pad[4];
+    unsigned pad[2];                     // [0] rounds beyond the first, [1] why the block is redone (statistics)
+    double thrP;                         // provisional threshold (predicted median x scale), thrA <= thrP <= thrB
 };
 static_assert(sizeof(MrtPar) == MRT_PARW * 4, "parameter record");
 
@@ -182,6 +185,10 @@ k_mr_predict(const float* __restrict__ resid, const uint8_t* __restrict__ flags_
         const unsigned kA = lo + ((dlo - 1u) << S), kB = kB64 > 0x7F7FFFFFull ? 0x7F7FFFFFu : (unsigned)kB64;
         p.thrA = (double)__uint_as_float(kA) * scale;
         p.thrB = (double)__uint_as_float(kB) * scale;
+        // the middle of the predicted bin: what the pass decides the bracket's samples by until the exact median is known
+        const unsigned long long kP64 = (unsigned long long)lo + ((unsigned long long)(bp > 0u ? bp - 1u : 0u) << S) + ((1ull << S) >> 1);
+        const unsigned kP = min(max((unsigned)min(kP64, 0x7F7FFFFFull), kA), kB);
+        p.thrP = (double)__uint_as_float(kP) * scale;
         p.status = 1;
         *par = p;
     }
@@ -203,6 +210,9 @@ k_mr_pass(const float* __restrict__ resid, const uint8_t* __restrict__ flags_in,
     const size_t win = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tx = lane, ty = wave;
+    // second round: a window none of whose blocks asked for it is left before anything else is looked up (0.36 ms per launch
+    // for 282 k workgroups that each searched their chunk and read their block's status just to find it done)
+    if (round == 2 && !(reinterpret_cast<const MrtPar*>(gscratch + win * scratch_ws)->pad[0] & MRT_ANY_ROUND2)) return;
     // the tile's chunk and first row: grid.y counts 64-row groups chunk by chunk
     int g = 0, l0 = 0, c1 = 0;
     {
@@ -223,7 +233,7 @@ k_mr_pass(const float* __restrict__ resid, const uint8_t* __restrict__ flags_in,
     __syncthreads();
     if (sh_status != round) return;                                    // (uniform) not this round's block
     const unsigned lo = par->lo, S = par->S, wlo = par->wlo, wspan = par->whi - par->wlo;
-    const double thrA = par->thrA, thrB = par->thrB;
+    const double thrA = par->thrA, thrB = par->thrB, thrP = par->thrP;
     const int w0 = blockIdx.x * 64, w = w0 + tx;
     const float4* r4 = reinterpret_cast<const float4*>(resid + win * ws_resid);
     const unsigned* fin = reinterpret_cast<const unsigned*>(flags_in + win * ws_flags);
@@ -279,9 +289,12 @@ k_mr_pass(const float* __restrict__ resid, const uint8_t* __restrict__ flags_in,
                 }
             }
             const double dx = (double)xv[k4];
-            const bool gtB = dx > thrB, gtA = dx > thrA;               // (a NaN compares false twice: never flagged)
-            fn |= gtB ? (1u << (8 * k4)) : 0u;
-            const bool und = valid && gtA && !gtB;
+            // decided: x > thrB flagged, x <= thrA not; between them (the undecided ~1 %, listed for k_mr_finish) the PROVISIONAL threshold
+            // decides for now -- the finish then only rewrites the few samples between it and the exact one
+            // (a NaN compares false every time: never flagged, never listed)
+            const bool gtB = dx > thrB, gtA = dx > thrA, gtP = dx > thrP;
+            fn |= gtP ? (1u << (8 * k4)) : 0u;
+            const bool und = unfl && gtA && !gtB;
             const unsigned long long um = __builtin_amdgcn_ballot_w64(und);
             if (um) {
                 const unsigned pos = ucnt + __builtin_amdgcn_mbcnt_hi((unsigned)(um >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)um, 0u));
@@ -356,7 +369,7 @@ k_mr_finish(const float* __restrict__ resid, const uint8_t* __restrict__ flags_i
     MrtPar* par = lay.par(g);
     if (par->status != round) return;                                  // (uniform: nothing writes it while this kernel runs but this workgroup)
     const unsigned wlo = par->wlo, whi = par->whi, nc = par->ncand, nu = par->nund, below1 = par->below1;
-    const double thrA = par->thrA, thrB = par->thrB;
+    const double thrA = par->thrA, thrB = par->thrB, thrP = par->thrP;
     const unsigned* ghist = lay.hist(g);
 #pragma unroll
     for (int u = 0; u < SEL_BINS / 256; u++) hist[u * 256 + tid] = ghist[u * 256 + tid];
@@ -418,8 +431,11 @@ k_mr_finish(const float* __restrict__ resid, const uint8_t* __restrict__ flags_i
             par->wlo = nlo; par->whi = nhi;
             par->thrA = (double)__uint_as_float(kA) * scale;
             par->thrB = (double)__uint_as_float(kB) * scale;
+            const unsigned long long kP64 = (unsigned long long)lo + ((unsigned long long)(bsel - 1u) << S) + ((1ull << S) >> 1);
+            par->thrP = (double)__uint_as_float(min(max((unsigned)min(kP64, 0x7F7FFFFFull), kA), kB)) * scale;
             par->ncand = 0; par->nund = 0; par->below1 = 0;
-            par->pad[0] += 1;                                           // (statistics: rounds beyond the first)
+            atomicAdd(&par->pad[0], 1u);                                // (statistics: rounds beyond the first)
+            atomicOr(&lay.par(0)->pad[0], MRT_ANY_ROUND2);              // this window has work for the second round's launches
             atomicAdd(&g_medrej_stats[3], 1ull);
             par->status = 2;
         }
@@ -469,10 +485,14 @@ k_mr_finish(const float* __restrict__ resid, const uint8_t* __restrict__ flags_i
     const unsigned T = (unsigned)C4 * 4u;
     for (unsigned j = tid; j < nu; j += 256) {
         const uint2 e = gu[j];
-        if ((double)__uint_as_float(e.y) > thr) {
+        // (listed samples were unflagged on input and carry the provisional decision x > thrP: only a different exact decision is written)
+        const double x = (double)__uint_as_float(e.y);
+        const bool d = x > thr;
+        if (d != (x > thrP)) {
             const unsigned l = e.x / T, t = e.x - l * T;
-            fo8[e.x] = 1;
-            ft8[((size_t)(t >> 2) * L + l) * 4 + (t & 3u)] = 1;
+            const uint8_t v = d ? 1 : 0;
+            fo8[e.x] = v;
+            ft8[((size_t)(t >> 2) * L + l) * 4 + (t & 3u)] = v;
         }
     }
     if (tid == 0) par->status = 3;                                      // done
