@@ -25,7 +25,10 @@ KNOBS = [(), ("TRI_FILTER_NO_PIPE_T", "TRI_FILTER_NO_PIPE_F"), ("TRI_MEDIAN_NO_P
          ("TRI_NO_FUSED_BEGIN", "TRI_NO_FT_SPEC_OR", "TRI_NO_FUSED_DILATE", "TRI_NO_FUSED_REJECT"),
          ("TRI_FILTER_NO_REGRING", "TRI_FILTER_NO_REGRING_F", "TRI_FILTER_NO_PIPE_T", "TRI_FILTER_NO_PIPE_F"),
          ("TRI_FILTER_NO_EXACT", "TRI_ST_NO_PIPE"), ("TRI_BOXX_NTI=256",), ("TRI_FILTER_NO_TF_REJECT",),
-         ("TRI_FILTER_PIPE_T_B8=0", "TRI_FILTER_PIPE_F_B8=0")]
+         ("TRI_FILTER_PIPE_T_B8=0", "TRI_FILTER_PIPE_F_B8=0"),
+         # round 4: integer weight filter, column panels, one-pass rejection (tile form / off / one workgroup per block / forced redo), wave medians
+         ("TRI_FILTER_NO_BOXW", "TRI_ST_NO_PANEL"), ("TRI_NO_TILE_MEDREJ",), ("TRI_FUSED_MEDREJ",), ("TRI_MEDREJ_FORCE_FALLBACK",),
+         ("TRI_MEDIAN_WAVE_OLD",)]
 ap = argparse.ArgumentParser(); ap.add_argument("--bl", type=int, default=252); ap.add_argument("--params", default="stage1")
 a = ap.parse_args()
 ref = None
