@@ -1180,6 +1180,8 @@ for shape, kw in (((2, 1, 64, 128), dict(num_major_iterations=2)),
                   ((1, 2, 100, 144), dict(num_major_iterations=2, background_iterations=2, spike_width_time=20.0,
                                           spike_width_freq=15.0)),
                   ((1, 1, 52, 300), dict(num_major_iterations=1, windows_freq=[1, 2, 4, 8, 16])),
+                  # final_st_very_broad's frequency windows on three chunks (the stage pipeline K7p, windows wider than a chunk's share of the line)
+                  ((1, 1, 24, 700), dict(num_major_iterations=1, windows_freq=[32, 48, 64, 128], freq_chunks=3)),
                   # frequency radii 110 / 55: the exact row filter K4x (short chunks; long chunks on the 2048-channel lines)
                   ((1, 2, 40, 512), dict(num_major_iterations=2, background_iterations=2, spike_width_freq=64.0)),
                   ((1, 1, 16, 2048), dict(num_major_iterations=1, background_iterations=2, spike_width_freq=64.0))):
