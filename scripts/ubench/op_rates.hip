@@ -8,6 +8,8 @@ template <int OP>
 __global__ void k(double* out, float seed, int waves_note) {
     double a0 = seed, a1 = seed + 1, a2 = seed + 2, a3 = seed + 3, a4 = seed + 4, a5 = seed + 5, a6 = seed + 6, a7 = seed + 7;
     float f0 = seed, f1 = seed + 1, f2 = seed + 2, f3 = seed + 3, f4 = seed + 4, f5 = seed + 5, f6 = seed + 6, f7 = seed + 7;
+    unsigned s0 = (unsigned)waves_note, s1 = s0 + 1, s2 = s0 + 2, s3 = s0 + 3, s4 = s0 + 4, s5 = s0 + 5, s6 = s0 + 6, s7 = s0 + 7;
+    unsigned long long m0 = (unsigned long long)waves_note * 0x9E3779B97F4A7C15ull, m1 = ~m0, m2 = m0 >> 7, m3 = m0 << 9, m4 = m0 ^ 0x5555555555555555ull, m5 = ~m4;
     long long t0 = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < N_IT; i++) {
         if (OP == 0) {  // v_add_f64, 8 independent chains
@@ -48,9 +50,26 @@ __global__ void k(double* out, float seed, int waves_note) {
             asm volatile("v_accvgpr_write_b32 a0, %0\n v_accvgpr_read_b32 %1, a0\n v_accvgpr_write_b32 a1, %2\n v_accvgpr_read_b32 %3, a1\n"
                          "v_accvgpr_write_b32 a2, %4\n v_accvgpr_read_b32 %5, a2\n v_accvgpr_write_b32 a3, %6\n v_accvgpr_read_b32 %7, a3\n"
                          : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7) : : "a0", "a1", "a2", "a3");
+        } else if (OP == 9) {  // scalar ALU, 8 independent 32-bit adds (round 4: is the scalar unit per SIMD or per CU?)
+            asm volatile("s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n s_add_u32 %2, %2, 1\n s_add_u32 %3, %3, 1\n"
+                         "s_add_u32 %4, %4, 1\n s_add_u32 %5, %5, 1\n s_add_u32 %6, %6, 1\n s_add_u32 %7, %7, 1\n"
+                         : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+s"(s4), "+s"(s5), "+s"(s6), "+s"(s7) : : "scc");
+        } else if (OP == 10) {  // 64-bit lane-mask algebra (the SumThreshold kernel's flag rings): s_or_b64 / s_and_b64
+            asm volatile("s_or_b64 %0, %0, %4\n s_and_b64 %1, %1, %4\n s_or_b64 %2, %2, %4\n s_and_b64 %3, %3, %4\n"
+                         "s_or_b64 %0, %0, %5\n s_and_b64 %1, %1, %5\n s_or_b64 %2, %2, %5\n s_and_b64 %3, %3, %5\n"
+                         : "+s"(m0), "+s"(m1), "+s"(m2), "+s"(m3) : "s"(m4), "s"(m5) : "scc");
+        } else if (OP == 11) {  // half vector, half scalar: v_add_f32 x4 + s_or_b64 x4 (do the two units overlap?)
+            asm volatile("v_add_f32 %0, %0, %8\n s_or_b64 %4, %4, %9\n v_add_f32 %1, %1, %8\n s_and_b64 %5, %5, %9\n"
+                         "v_add_f32 %2, %2, %8\n s_or_b64 %6, %6, %9\n v_add_f32 %3, %3, %8\n s_and_b64 %7, %7, %9\n"
+                         : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+s"(m0), "+s"(m1), "+s"(m2), "+s"(m3) : "v"(1.5f), "s"(m4) : "scc");
+        } else if (OP == 12) {  // compare into a lane mask + mask algebra + mask back into a select: v_cmp_gt_f32, s_and_b64, v_cndmask x 2 + 2 more mask ops
+            asm volatile("v_cmp_gt_f32 %4, %0, %8\n s_and_b64 %4, %4, %5\n v_cndmask_b32 %1, %1, %0, %4\n s_or_b64 %6, %6, %4\n"
+                         "v_cmp_lt_f32 %7, %2, %8\n s_and_b64 %7, %7, %5\n v_cndmask_b32 %3, %3, %2, %7\n s_or_b64 %6, %6, %7\n"
+                         : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+s"(m0), "+s"(m1), "+s"(m2), "+s"(m3) : "v"(1.5f) : "scc");
         }
     }
     long long t1 = __builtin_amdgcn_s_memtime();
+    if ((s0 + s1 + s2 + s3 + s4 + s5 + s6 + s7) == 0x7fffffffu && (m0 ^ m1 ^ m2 ^ m3) == 0x123456789ull) out[3] = 1.0;
     double s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7;
     if (threadIdx.x == 0) out[blockIdx.x * 2] = (double)(t1 - t0) / (N_IT * 8.0);
     if (s == 12345.678) out[1] = s;
@@ -88,5 +107,9 @@ int main() {
     run<6>("v_fma_f32 x8");
     run<7>("ieee div mix (8 ops)");
     run<8>("accvgpr write/read");
+    run<9>("s_add_u32 x8 indep");
+    run<10>("s_or_b64 / s_and_b64 x8");
+    run<11>("v_add_f32 x4 + s_or/and_b64 x4");
+    run<12>("v_cmp -> s_and -> v_cndmask -> s_or x2");
     return 0;
 }
