@@ -66,6 +66,18 @@ __global__ void k(double* out, float seed, int waves_note) {
             asm volatile("v_cmp_gt_f32 %4, %0, %8\n s_and_b64 %4, %4, %5\n v_cndmask_b32 %1, %1, %0, %4\n s_or_b64 %6, %6, %4\n"
                          "v_cmp_lt_f32 %7, %2, %8\n s_and_b64 %7, %7, %5\n v_cndmask_b32 %3, %3, %2, %7\n s_or_b64 %6, %6, %7\n"
                          : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+s"(m0), "+s"(m1), "+s"(m2), "+s"(m3) : "v"(1.5f) : "scc");
+        } else if (OP == 13) {  // eight independent float64 compares into lane masks (throughput of VALU -> SGPR results)
+            asm volatile("v_cmp_gt_f64 %0, %4, %5\n v_cmp_lt_f64 %1, %4, %5\n v_cmp_gt_f64 %2, %5, %4\n v_cmp_lt_f64 %3, %5, %4\n"
+                         "v_cmp_gt_f64 %0, %4, %6\n v_cmp_lt_f64 %1, %4, %6\n v_cmp_gt_f64 %2, %6, %4\n v_cmp_lt_f64 %3, %6, %4\n"
+                         : "=s"(m0), "=s"(m1), "=s"(m2), "=s"(m3) : "v"(a0), "v"(a1), "v"(a2));
+        } else if (OP == 14) {  // eight selects by lane masks held in scalar registers (throughput of SGPR-mask operands)
+            asm volatile("v_cndmask_b32 %0, %0, %4, %8\n v_cndmask_b32 %1, %1, %4, %9\n v_cndmask_b32 %2, %2, %4, %10\n v_cndmask_b32 %3, %3, %4, %11\n"
+                         "v_cndmask_b32 %0, %0, %5, %9\n v_cndmask_b32 %1, %1, %5, %10\n v_cndmask_b32 %2, %2, %5, %11\n v_cndmask_b32 %3, %3, %5, %8\n"
+                         : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(f4), "v"(f5), "v"(f6), "v"(f7), "s"(m0), "s"(m1), "s"(m2), "s"(m3));
+        } else if (OP == 15) {  // float32 compares into lane masks
+            asm volatile("v_cmp_gt_f32 %0, %4, %5\n v_cmp_lt_f32 %1, %4, %5\n v_cmp_gt_f32 %2, %5, %4\n v_cmp_lt_f32 %3, %5, %4\n"
+                         "v_cmp_gt_f32 %0, %4, %6\n v_cmp_lt_f32 %1, %4, %6\n v_cmp_gt_f32 %2, %6, %4\n v_cmp_lt_f32 %3, %6, %4\n"
+                         : "=s"(m0), "=s"(m1), "=s"(m2), "=s"(m3) : "v"(f0), "v"(f1), "v"(f2));
         }
     }
     long long t1 = __builtin_amdgcn_s_memtime();
@@ -111,5 +123,8 @@ int main() {
     run<10>("s_or_b64 / s_and_b64 x8");
     run<11>("v_add_f32 x4 + s_or/and_b64 x4");
     run<12>("v_cmp -> s_and -> v_cndmask -> s_or x2");
+    run<13>("v_cmp_f64 -> lane mask x8 indep");
+    run<14>("v_cndmask by scalar masks x8");
+    run<15>("v_cmp_f32 -> lane mask x8 indep");
     return 0;
 }
