@@ -44,3 +44,53 @@ def test_failing_rank_reaches_the_caller_as_a_nonzero_exit():
         assert p.returncode != 0, (failing, p.stdout[-500:], p.stderr[-500:])
         if failing == 0:
             assert '"scatter": {"error"' in p.stdout          # the headline line still came out
+
+
+def _bench():
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench
+
+
+def test_dominant_leg_is_derived_from_the_kernel_log():
+    """`roofline` is the measured leg whose kernel FAMILY has the largest share of the step --
+    launches of the family in one step (the library's kernel log) / launches per measurement x measured ms."""
+    bench = _bench()
+    legs = [dict(device_kernels=["k_colst_mask<1, 2, 4, 8, true>"], launches_per_measurement=1, ms_per_launch=5.3, frac=0.5),
+            dict(device_kernels=["k_boxqf<80, 1, 8>"], launches_per_measurement=1, ms_per_launch=17.5, frac=0.48),
+            dict(device_kernels=["k_boxq_deep<96, 1>", "k_boxw<108>"], launches_per_measurement=2, ms_per_launch=15.0, frac=0.46),
+            dict(device_kernels=["k_median_reject", "k_mr_finish", "k_mr_pass", "k_mr_predict"], launches_per_measurement=6, ms_per_launch=7.8, frac=0.47),
+            dict(error="not measured")]
+    step = {"k_boxqf<80, 1, 8>": 5, "k_boxqf<64, 1, 8>": 5, "k_boxqf<48, 1, 8>": 5, "k_boxqf<32, 1, 8>": 5,
+            "k_colst_mask<1, 2, 4, 8, true>": 5, "k_colst_mask<1, 2, 4, 8, false>": 5,
+            "k_boxq_deep<96, 1>": 5, "k_boxq<80, 1, 8>": 5, "k_boxw<108>": 5, "k_boxw<86>": 5,
+            "k_mr_predict": 25, "k_mr_pass<false>": 50, "k_mr_finish": 50, "k_median_reject": 25}
+    dom, shares = bench.pick_dominant(legs, step)
+    assert dom["device_kernels"] == ["k_boxqf<80, 1, 8>"] and dom["step_family_launches"] == 20
+    assert abs(dom["step_share_ms_estimate"] - 350.0) < 1e-6
+    by = {tuple(e["device_kernels"]): e for _, e in shares}
+    assert by[("k_colst_mask<1, 2, 4, 8, true>",)]["step_family_launches"] == 10
+    assert by[("k_median_reject", "k_mr_finish", "k_mr_pass", "k_mr_predict")]["step_family_launches"] == 150
+    assert abs(by[("k_median_reject", "k_mr_finish", "k_mr_pass", "k_mr_predict")]["step_share_ms_estimate"] - 195.0) < 1e-6
+    # a step dominated by the rejection loop names that leg
+    dom2, _ = bench.pick_dominant(legs, {"k_mr_pass": 500, "k_boxqf<80, 1, 8>": 1})
+    assert dom2["device_kernels"][0] == "k_median_reject"
+
+
+def test_pmc_traffic_only_for_the_same_kernels_size_and_build(tmp_path, monkeypatch):
+    """a committed PMC file counts only for the kernel symbols it was recorded for, the same launch size
+    and the same build of the kernel sources (lib_sha16); anything else reports traffic = null."""
+    bench = _bench()
+    from tricolour_amd import _lib
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    rec = dict(device_kernels=["k_a<1>", "k_b"], samples_per_launch=1000, lib_sha16=_lib.source_hash(), hbm_bytes_per_launch=5150)
+    (prof / "r04_pmc_leg.json").write_text(json.dumps(rec))
+    assert bench._pmc_traffic("leg", 1000, ["k_b", "k_a<1>"]) == (5150, "profiles/r04_pmc_leg.json")
+    assert bench._pmc_traffic("leg", 1000, ["k_a<2>", "k_b"]) == (None, None)        # other kernels
+    assert bench._pmc_traffic("leg", 2000, ["k_a<1>", "k_b"]) == (None, None)        # other launch size
+    assert bench._pmc_traffic("other", 1000, ["k_a<1>", "k_b"]) == (None, None)      # no file
+    rec["lib_sha16"] = "0123456789abcdef"
+    (prof / "r04_pmc_leg.json").write_text(json.dumps(rec))
+    assert bench._pmc_traffic("leg", 1000, ["k_a<1>", "k_b"]) == (None, None)        # recorded for another build
