@@ -687,6 +687,81 @@ def test_rejection_step_hook_vs_numpy(gpu, n_win, F, T, ends, reject):
     assert ms.value > 0
 
 
+@pytest.mark.parametrize("kind", ["bimodal", "cauchy", "mostly_flagged", "constant", "plateau", "zeros", "wide_exponents",
+                                  "ramp", "near_power_of_two", "inf_nan", "two_values", "tiny_sample"])
+def test_rejection_step_adversarial_distributions(gpu, kind):
+    """The one-pass rejection step (prediction from 4 % of a block, provisional threshold, second round, redo) on
+    residual distributions built to break a prediction: two populations, heavy tails, almost everything flagged, a
+    constant block, a plateau of equal values around the median, exact zeros, 80 binary orders of magnitude, a sorted
+    ramp (the sampled runs are not representative), values hugging a power of two, unflagged infinities and NaNs.
+    Whatever route a block takes, flags (both layouts) and medians must equal numpy's."""
+    import ctypes as C
+    import torch
+    from tricolour_amd import _lib
+    rs = np.random.RandomState(sum(map(ord, kind)))
+    n_win, F, T, ends, reject = 2, 300, 1024, [0, 100, 170, 300], 2.0
+    shape = (n_win, F, T)
+    x = np.abs(rs.standard_normal(shape)).astype(np.float32)
+    flags = rs.uniform(size=shape) < 0.05
+    if kind == "bimodal":
+        x[:, :, : T // 2] *= np.float32(100.0)
+        x[1, :150] *= np.float32(1e-3)
+    elif kind == "cauchy":
+        x = np.abs(rs.standard_cauchy(shape)).astype(np.float32)
+    elif kind == "mostly_flagged":
+        flags = rs.uniform(size=shape) < 0.97
+        flags[1, 100:170] = rs.uniform(size=(70, T)) < 0.999
+    elif kind == "constant":
+        x[0] = np.float32(2.5)
+        x[1, :100] = np.float32(0.0)
+    elif kind == "plateau":
+        x[rs.uniform(size=shape) < 0.52] = np.float32(0.71875)
+    elif kind == "zeros":
+        x[rs.uniform(size=shape) < 0.6] = np.float32(0.0)
+    elif kind == "wide_exponents":
+        x = (x * np.exp2(rs.randint(-40, 41, size=shape)).astype(np.float32)).astype(np.float32)
+    elif kind == "ramp":
+        x = np.sort(x.reshape(n_win, -1), axis=1).reshape(shape)
+        x[1] = x[1, ::-1, ::-1]
+    elif kind == "near_power_of_two":
+        x = (np.float32(1.0) + (x * np.float32(1e-6))).astype(np.float32)
+        x[1] = (np.float32(2.0) - x[1] * np.float32(1e-7)).astype(np.float32)
+    elif kind == "inf_nan":
+        x[rs.uniform(size=shape) < 1e-3] = np.inf
+        x[rs.uniform(size=shape) < 1e-3] = np.nan
+    elif kind == "two_values":
+        x = np.where(rs.uniform(size=shape) < 0.5, np.float32(1.0), np.float32(3.0)).astype(np.float32)
+    elif kind == "tiny_sample":
+        # unflagged samples only where the prediction does not look: its runs find (almost) nothing
+        flags[:] = True
+        flags[:, ::7, 900:] = False
+    G = len(ends) - 1
+    exp_med = np.empty((n_win, G))
+    exp = flags.copy()
+    for w in range(n_win):
+        for g in range(G):
+            blk = (w, slice(ends[g], ends[g + 1]))
+            m = _np_median_abs(x[blk][~flags[blk]])                     # (np.sort puts NaNs last: the key order of the select)
+            exp_med[w, g] = m
+            with np.errstate(invalid="ignore"):
+                exp[blk] |= x[blk].astype(np.float64) > m * (1.4826 * reject)
+    d = torch.from_numpy(x).cuda()
+    f = torch.from_numpy(flags).cuda().view(torch.uint8)
+    fo = torch.full(shape, 0xEE, dtype=torch.uint8, device="cuda")
+    t4 = torch.full((n_win, T // 4, F, 4), 0xDD, dtype=torch.uint8, device="cuda")
+    med = torch.full((n_win, G), -1.0, dtype=torch.float64, device="cuda")
+    e = (C.c_int64 * len(ends))(*ends)
+    ms = C.c_float(0)
+    _lib.check(_lib.lib().tri_bench_reject(d.data_ptr(), f.data_ptr(), fo.data_ptr(), t4.data_ptr(), med.data_ptr(), n_win, F, T,
+                                           e, len(ends), reject, 1, C.byref(ms), None))
+    got_med = med.cpu().numpy()
+    assert ((got_med == exp_med) | (np.isnan(got_med) & np.isnan(exp_med))).all(), (kind, got_med, exp_med)
+    got = fo.cpu().numpy()
+    assert np.array_equal(got != 0, exp), "%s: %d FT flags differ" % (kind, ((got != 0) != exp).sum())
+    got4 = t4.cpu().numpy().transpose(0, 2, 1, 3).reshape(shape)
+    assert np.array_equal(got4 != 0, exp), "%s: %d TF4 flags differ" % (kind, ((got4 != 0) != exp).sum())
+
+
 EDGE_CASES = [
     # (shape, kwargs)
     ((1, 1, 1, 16), dict(num_major_iterations=1)),
